@@ -1,0 +1,902 @@
+// TEST INFRASTRUCTURE — the CPU oracle (liborc.so).
+//
+// A from-scratch fp64 restatement of the reference's eye pass, written from SURVEY.md §8a and
+// the reference sources read as text.  It exists only to CHECK the HIP path: only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+// (cgraytracing_amd/, include/cgrt.h) never links, imports or falls back to anything here.
+//
+// Parity status: PINNED.  tests/test_oracle_vs_golden.py compares this file against golden
+// vectors generated from the compiled, unmodified reference (oracle/_ref, tests/golden/make_golden.py)
+// and, where oracle/_ref/libcgrt_ref.so is present, against the reference run live.
+//
+// Written in C++ rather than C because quirk Q5 needs libstdc++ std::sort's exact tie behaviour
+// (objects.h:254-260); everything else is plain scalar code.
+//
+// Citations are to /root/reference/<file>:<line>.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <omp.h>
+
+#include "cgrt_rng.h"
+#include "cgrt_testapi.h"
+
+namespace orc {
+
+// ---------------------------------------------------------------- vec3.h:11-119
+struct V3 {
+    double x, y, z;
+    V3(double a = 0, double b = 0, double c = 0) : x(a), y(b), z(c) {}
+};
+static inline V3 operator+(const V3 &a, const V3 &b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(const V3 &a, const V3 &b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator-(const V3 &a) { return V3(-a.x, -a.y, -a.z); }
+static inline V3 operator*(const V3 &a, double f) { return V3(a.x * f, a.y * f, a.z * f); }
+static inline V3 mul(const V3 &a, const V3 &b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 cross(const V3 &a, const V3 &b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline double norm(const V3 &a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+// vec3.h:36-44: scales by 1/len only when len > 0
+static inline V3 normalized(V3 a) {
+    double len = norm(a);
+    if (len > 0) {
+        a.x *= 1 / len;
+        a.y *= 1 / len;
+        a.z *= 1 / len;
+    }
+    return a;
+}
+// vec3.h:95-97 (Sarrus, this exact association)
+static inline double det3(const V3 &a, const V3 &b, const V3 &c) {
+    return (a.x * b.y * c.z + b.x * c.y * a.z + c.x * a.y * b.z - a.x * c.y * b.z - b.x * a.y * c.z -
+            c.x * b.y * a.z);
+}
+// vec3.h:103-119
+static inline bool inv3(const V3 &a, const V3 &b, const V3 &c, V3 &ra, V3 &rb, V3 &rc) {
+    double d = det3(a, b, c);
+    if (d < 1e-4 && d > -1e-4) return false;
+    ra.x = (b.y * c.z - b.z * c.y) / d;
+    ra.y = (c.y * a.z - c.z * a.y) / d;
+    ra.z = (a.y * b.z - a.z * b.y) / d;
+    rb.x = (c.x * b.z - c.z * b.x) / d;
+    rb.y = (a.x * c.z - a.z * c.x) / d;
+    rb.z = (b.x * a.z - b.z * a.x) / d;
+    rc.x = (b.x * c.y - c.x * b.y) / d;
+    rc.y = (c.x * a.y - c.y * a.x) / d;
+    rc.z = (a.x * b.y - a.y * b.x) / d;
+    return true;
+}
+// util.h:16-42
+static inline double max3(double a, double b, double c) { return (a > b && a > c) ? a : (b > c ? b : c); }
+static inline double min3(double a, double b, double c) { return (a < b && a < c) ? a : (b < c ? b : c); }
+
+static const double EPS = 1e-4;      // main.cpp:24
+static const double INF = 1e10;      // main.cpp:25, objects.h:15
+static const double BOXEPS = 1e-4;   // objects.h:144
+static const int MINKD = 10;         // objects.h:143
+
+// ---------------------------------------------------------------- keyed stream
+struct Rng {
+    uint64_t key;
+    uint32_t ctr;
+    double u01() { return (double)cgrt_rand31(key, ctr++) / 2147483647.0; }  // sampling.h:31-33
+};
+// sampling.h:35-43
+static V3 lens_sample(Rng &r, double radius) {
+    while (true) {
+        double x = r.u01() * 2.0 - 1;
+        double y = r.u01() * 2.0 - 1;
+        if (x * x + y * y < 1) return V3(x, y, 0) * radius;
+    }
+}
+
+// ---------------------------------------------------------------- objects.h:91-141
+struct Tri {
+    V3 pa, pb, pc;
+};
+// objects.h:96-111
+static inline bool tri_intersect(const Tri &t, const V3 &o, const V3 &d, double &len, V3 &n) {
+    V3 e1 = t.pa - t.pb, e2 = t.pa - t.pc, s = t.pa - o;
+    double det1 = det3(d, e1, e2), det2 = det3(s, e1, e2), det3_ = det3(d, s, e2), det4 = det3(d, e1, s);
+    if (det2 / det1 > 0.0 && det3_ / det1 >= 0.0 && det4 / det1 >= 0.0 && (det3_ + det4) / det1 <= 1.0) {
+        len = det2 / det1;
+        n = normalized(cross(t.pa - t.pb, t.pa - t.pc));
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- objects.h:147-332
+struct Node {
+    double xmax, xmin, ymax, ymin, zmax, zmin;
+    int left, right;
+    std::vector<int> ids;  // triangleList (ids into Tree::tris)
+};
+struct Tree {
+    std::vector<Tri> tris;  // construction order (pair.first)
+    std::vector<Node> nodes;
+
+    // objects.h:217-267.  The reference sorts vector<pair<int,Triangle>>; sorting the id list with a
+    // comparator that returns the same answers drives std::sort through the same moves (Q5).
+    void build(std::vector<int> sub, int par, bool isLeft, int dim, bool isRoot) {
+        int cur = (int)nodes.size();
+        if (!isRoot) (isLeft ? nodes[par].left : nodes[par].right) = cur;
+        nodes.push_back(Node());
+        {
+            Node &nd = nodes[cur];
+            nd.ids = sub;  // copied BEFORE sorting (Q7)
+            nd.xmax = nd.ymax = nd.zmax = -INF;
+            nd.xmin = nd.ymin = nd.zmin = INF;
+            for (size_t i = 0; i < sub.size(); i++) {
+                const Tri &a = tris[sub[i]];
+                double mxx = max3(a.pa.x, a.pb.x, a.pc.x), mxy = max3(a.pa.y, a.pb.y, a.pc.y),
+                       mxz = max3(a.pa.z, a.pb.z, a.pc.z);
+                double mnx = min3(a.pa.x, a.pb.x, a.pc.x), mny = min3(a.pa.y, a.pb.y, a.pc.y),
+                       mnz = min3(a.pa.z, a.pb.z, a.pc.z);
+                if (nd.xmax < mxx) nd.xmax = mxx;
+                if (nd.ymax < mxy) nd.ymax = mxy;
+                if (nd.zmax < mxz) nd.zmax = mxz;
+                if (nd.xmin > mnx) nd.xmin = mnx;
+                if (nd.ymin > mny) nd.ymin = mny;
+                if (nd.zmin > mnz) nd.zmin = mnz;
+            }
+            nd.left = nd.right = -1;
+        }
+        if ((int)sub.size() < MINKD) return;
+        const std::vector<Tri> &T = tris;
+        if (dim == 0)
+            std::sort(sub.begin(), sub.end(), [&T](int p, int q) {
+                return max3(T[p].pa.x, T[p].pb.x, T[p].pc.x) < max3(T[q].pa.x, T[q].pb.x, T[q].pc.x);
+            });
+        else if (dim == 1)
+            std::sort(sub.begin(), sub.end(), [&T](int p, int q) {
+                return max3(T[p].pa.y, T[p].pb.y, T[p].pc.y) < max3(T[q].pa.y, T[q].pb.y, T[q].pc.y);
+            });
+        else
+            std::sort(sub.begin(), sub.end(), [&T](int p, int q) {
+                return max3(T[p].pa.z, T[p].pb.z, T[p].pc.z) < max3(T[q].pa.z, T[q].pb.z, T[q].pc.z);
+            });
+        std::vector<int> l(sub.begin(), sub.begin() + sub.size() / 2), r(sub.begin() + sub.size() / 2, sub.end());
+        int nd = (dim + 1) % 3;
+        build(l, cur, true, nd, false);
+        build(r, cur, false, nd, false);
+    }
+    void build_all() {
+        std::vector<int> all(tris.size());
+        for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+        nodes.clear();
+        build(all, 0, false, 0, true);
+    }
+
+    // objects.h:166-200: six face tests, in this order
+    static bool box_hit(const Node &b, const V3 &o, const V3 &d) {
+        double t;
+        V3 p;
+        t = (b.xmax - o.x) / d.x; p = o + d * t;
+        if (t > 0 && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) return true;
+        t = (b.xmin - o.x) / d.x; p = o + d * t;
+        if (t > 0 && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) return true;
+        t = (b.ymax - o.y) / d.y; p = o + d * t;
+        if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) return true;
+        t = (b.ymin - o.y) / d.y; p = o + d * t;
+        if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) return true;
+        t = (b.zmax - o.z) / d.z; p = o + d * t;
+        if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS) return true;
+        t = (b.zmin - o.z) / d.z; p = o + d * t;
+        if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS) return true;
+        return false;
+    }
+    // objects.h:269-316.  Returns the number of times the running minimum improved (Q5), visits both
+    // children unconditionally (Q6).
+    int subtree(const V3 &o, const V3 &d, double &len, V3 &n, int cur, uint64_t *stats) const {
+        const Node &nd = nodes[cur];
+        if (stats) stats[0]++;
+        if (!box_hit(nd, o, d)) return 0;
+        if ((int)nd.ids.size() < MINKD) {
+            double lt;
+            V3 nt;
+            int counter = 0;
+            len = INF;
+            for (size_t i = 0; i < nd.ids.size(); i++) {
+                if (stats) stats[1]++;
+                if (tri_intersect(tris[nd.ids[i]], o, d, lt, nt)) {
+                    if (lt < len) {
+                        len = lt;
+                        n = nt;
+                        counter++;
+                    }
+                }
+            }
+            return counter;
+        }
+        double ll, lr;
+        V3 nl, nr;
+        int cl = subtree(o, d, ll, nl, nd.left, stats);
+        int cr = subtree(o, d, lr, nr, nd.right, stats);
+        if (cl > 0) {
+            if (cr > 0) {
+                if (ll < lr) { len = ll; n = nl; } else { len = lr; n = nr; }
+            } else { len = ll; n = nl; }
+        } else if (cr > 0) { len = lr; n = nr; }
+        return cl + cr;
+    }
+    // objects.h:318-332
+    bool intersect(const V3 &o, const V3 &d, double &len, V3 &n, uint64_t *stats) const {
+        int counter = subtree(o, d, len, n, 0, stats);
+        if (counter > 0) {
+            if (counter % 2 == 0) n = n * ((dot(n, d) < 0) ? 1 : -1);
+            else n = n * ((dot(n, d) < 0) ? -1 : 1);
+            return true;
+        }
+        return false;
+    }
+};
+
+// ---------------------------------------------------------------- texture.h:14-83
+struct Texture {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> rgb;  // texel = byte/256 (main.cpp:303-316)
+    V3 normal, position;
+    double lenx = 0, leny = 0;
+    bool isbump = false;
+    std::vector<double> height;  // texture.h:26-37
+    V3 texel(int r, int c) const {
+        // the reference would index out of bounds here; clamp
+        r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+        c = c < 0 ? 0 : (c >= cols ? cols - 1 : c);
+        const uint8_t *p = &rgb[3 * ((size_t)r * cols + c)];
+        return V3((double)p[0] / 256.0, (double)p[1] / 256.0, (double)p[2] / 256.0);
+    }
+    void make_height() {
+        height.assign((size_t)rows * cols, 0.0);
+        if (!isbump) return;
+        for (int i = 0; i < rows; i++)
+            for (int j = 0; j < cols; j++) {
+                V3 d = texel(i, j);
+                double h = (0.299 * d.x + 0.587 * d.y + 0.114 * d.z);
+                h = 1 - std::exp(-3.3 * h);
+                h *= 0.5;
+                height[(size_t)i * cols + j] = h;
+            }
+    }
+    // texture.h:39-72
+    bool color(const V3 &point, V3 &out) const {
+        V3 d = point - position;
+        d = d - normal * dot(d, normal);
+        const double te = 1e-2;
+        if (d.x < te && d.x > -te) {
+            if (0 < d.y && d.y < lenx && 0 < d.z && d.z < leny) {
+                int id1 = (int)std::floor(d.y / lenx * rows);
+                int id2 = (int)std::floor(d.z / leny * cols);
+                out = texel(id1, id2);
+                return true;
+            }
+            return false;
+        } else if (d.y < te && d.y > -te) {
+            if (0 < d.x && d.x < lenx && 0 < d.z && d.z < leny) {
+                int id1 = (int)std::floor(d.x / lenx * cols);
+                int id2 = (int)std::floor(d.z / leny * rows);
+                out = texel(id2, id1);
+                return true;
+            }
+            return false;
+        } else if (d.z < te && d.z > -te) {
+            if (0 < d.x && d.x < lenx && 0 < d.y && d.y < leny) {
+                int id1 = (int)std::floor(d.x / lenx * cols);
+                int id2 = (int)std::floor(d.y / leny * rows);
+                out = texel(rows - 1 - id2, id1);
+                return true;
+            }
+            return false;
+        }
+        return false;
+    }
+};
+
+// ---------------------------------------------------------------- objects
+enum Kind { SPHERE, PLANE, MESH, BEZIER };
+struct Obj {
+    Kind kind;
+    V3 color;
+    double refl = 0, transp = 0;
+    // sphere (objects.h:83-88)
+    V3 center;
+    double radius = 0, radius2 = 0;
+    // plane (objects.h:541-547)
+    V3 position, normal;
+    int tex = -1;
+    bool has_bump_tree = false;
+    Tree bump;
+    // mesh (objects.h:470-475)
+    Tree tree;
+    int objtype = 0;
+    // bezier (bezier.h:303-313)
+    std::vector<V3> cp;
+    double xmax = 0, xmin = 0, ymax = 0, ymin = 0, zmax = 0, zmin = 0;
+};
+
+struct Scene {
+    std::vector<Obj *> objs;
+    std::vector<Texture *> textures;
+    std::vector<int> mesh_ids, plane_ids;
+    ~Scene() {
+        for (auto o : objs) delete o;
+        for (auto t : textures) delete t;
+    }
+};
+
+// objects.h:45-68
+static bool sphere_intersect(const Obj &s, const V3 &o, const V3 &d, double &len, V3 &n) {
+    V3 l = s.center - o;
+    double tca = dot(l, d);
+    double l2 = dot(l, l);
+    if (tca < 0 && l2 > s.radius2) return false;
+    double d2 = dot(l, l) - tca * tca;
+    if (d2 > s.radius2) return false;
+    double thc = std::sqrt(s.radius2 - d2);
+    double t0 = tca - thc, t1 = tca + thc;
+    len = (t0 < 0) ? t1 : t0;
+    V3 p = o + d * len;
+    n = normalized(p - s.center);
+    return true;
+}
+// objects.h:505-524
+static bool plane_intersect(const Scene &sc, const Obj &pl, const V3 &o, const V3 &d, double &len, V3 &n,
+                            uint64_t *stats) {
+    V3 dd = pl.position - o;
+    len = dot(dd, pl.normal) / dot(d, pl.normal);
+    if (len > 0) {
+        n = pl.normal;
+        double lenp;
+        V3 np;
+        bool isbump = pl.tex >= 0 && sc.textures[pl.tex]->isbump;  // Q4: default Texture => false
+        if (isbump && std::fabs(pl.normal.y - 1) < 1e-5 && pl.has_bump_tree && pl.bump.intersect(o, d, lenp, np, stats)) {
+            if (lenp < len && lenp > 0) {
+                len = lenp;
+                n = np;
+            }
+        }
+        return true;
+    }
+    return false;
+}
+// objects.h:405-455
+static bool mesh_intersect(const Obj &m, const V3 &o, const V3 &d, double &len, V3 &n, uint64_t *stats) {
+    bool res = m.tree.intersect(o, d, len, n, stats);
+    if (m.objtype == 2) n = n * ((dot(n, V3(0, 1, 0)) > 0) ? 1 : -1);
+    return res;
+}
+
+// ---------------------------------------------------------------- bezier.h
+static const double Cni[7][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0},
+                                 {1, 3, 3, 1, 0, 0, 0}, {1, 4, 6, 4, 1, 0, 0}, {1, 5, 10, 10, 5, 1, 0},
+                                 {1, 6, 15, 20, 15, 6, 1}};
+// bezier.h:30-40
+static double Bern(int n, int i, double t) {
+    if (i > n || i < 0) return 0;
+    return Cni[n][i] * std::pow(1 - t, (double)(n - i)) * std::pow(t, (double)i);
+}
+static double dBern(int n, int i, double t) { return Bern(n - 1, i - 1, t) * (double)i - Bern(n - 1, i, t) * (double)(n - i); }
+static V3 bez_valueP(const Obj &b, double u) {  // bezier.h:127-134
+    V3 res;
+    int n = (int)b.cp.size();
+    for (int i = 0; i < n; i++) res = res + b.cp[i] * Bern(n - 1, i, u);
+    return res;
+}
+static V3 bez_gradP(const Obj &b, double u) {  // bezier.h:135-142
+    V3 res;
+    int n = (int)b.cp.size();
+    for (int i = 0; i < n; i++) res = res + b.cp[i] * dBern(n - 1, i, u);
+    return res;
+}
+static V3 bez_func(const Obj &b, const V3 &p, const V3 &o, const V3 &d) {  // bezier.h:144-149
+    V3 t = bez_valueP(b, p.y);
+    t.x = t.z * std::sin(p.z);
+    t.z *= std::cos(p.z);
+    return o + d * p.x - b.position - t;
+}
+static void bez_grad(const Obj &b, const V3 &p, const V3 &d, V3 &ra, V3 &rb, V3 &rc) {  // bezier.h:150-162
+    ra = d;
+    V3 t1 = bez_gradP(b, p.y), t2 = bez_valueP(b, p.y);
+    rb.x = -std::sin(p.z) * t1.z;
+    rb.y = -t1.y;
+    rb.z = -std::cos(p.z) * t1.z;
+    rc.x = -std::cos(p.z) * t2.z;
+    rc.y = 0;
+    rc.z = std::sin(p.z) * t2.z;
+}
+static uint64_t g_jitter_events = 0;  // test observability only
+// bezier.h:163-214
+static V3 bez_newton(const Obj &b, const V3 &initial, const V3 &o, const V3 &dir, Rng &rng) {
+    V3 res = initial;
+    int counter = 0;
+    V3 a, bb, c, d, e, f;  // d,e,f start at zero and keep stale values when the Jacobian is singular (Q11)
+    V3 fv = bez_func(b, res, o, dir);
+    while (norm(fv) > 1e-6 && counter < 100) {
+        counter++;
+        bez_grad(b, res, dir, a, bb, c);
+        bool ok = inv3(a, bb, c, d, e, f);
+        if (!ok) {
+            g_jitter_events++;
+            // bezier.h:183: Vec3(u(),u(),u()) -- g++ evaluates the arguments right to left (pinned by
+            // tests/test_oracle_vs_ref.py::test_bezier_singular_jitter)
+            double uz = rng.u01(), uy = rng.u01(), ux = rng.u01();
+            V3 j = V3(ux, uy, uz) * 0.2;
+            res = V3(res.x + j.x - 0.1, res.y + j.y - 0.1, res.z + j.z - 0.1);
+        }
+        V3 step = (d * fv.x + e * fv.y) + f * fv.z;  // vec3.h:99-101
+        res = res - step;
+        fv = bez_func(b, res, o, dir);
+    }
+    return res;
+}
+// bezier.h:72-126 (nearest-face t unused; a face only counts when t < 1e10)
+static bool bez_box(const Obj &b, const V3 &o, const V3 &d) {
+    double len = INF, t;
+    bool flag = false;
+    V3 p;
+    t = (b.xmax - o.x) / d.x; p = o + d * t;
+    if (t > 0 && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) if (t < len) { len = t; flag = true; }
+    t = (b.xmin - o.x) / d.x; p = o + d * t;
+    if (t > 0 && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) if (t < len) { len = t; flag = true; }
+    t = (b.ymax - o.y) / d.y; p = o + d * t;
+    if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) if (t < len) { len = t; flag = true; }
+    t = (b.ymin - o.y) / d.y; p = o + d * t;
+    if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) if (t < len) { len = t; flag = true; }
+    t = (b.zmax - o.z) / d.z; p = o + d * t;
+    if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS) if (t < len) { len = t; flag = true; }
+    t = (b.zmin - o.z) / d.z; p = o + d * t;
+    if (t > 0 && p.x >= b.xmin - BOXEPS && p.x <= b.xmax + BOXEPS && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS) if (t < len) { len = t; flag = true; }
+    return flag;
+}
+// bezier.h:225-290.  `n` is the caller's running normal (stale value is re-oriented when nothing hits,
+// harmless because the return value is then false).
+static bool bezier_intersect(const Obj &b, const V3 &o, const V3 &d, double &len, V3 &n, Rng &rng) {
+    if (!bez_box(b, o, d)) return false;
+    bool flag = false;
+    len = INF;
+    for (int i = 0; i < 10; i++) {
+        double u0 = rng.u01();
+        double t0 = 20 + 10 * rng.u01();
+        V3 p = o + d * t0;
+        p = p - b.position;
+        double theta = (p.z < 0) ? 3.14159265 + std::atan(p.x / p.z) : std::atan(p.x / p.z);
+        V3 res = bez_newton(b, V3(t0, u0, theta), o, d, rng);
+        if (norm(bez_func(b, res, o, d)) < 1e-4 && res.x > 0 && res.y <= 1 && res.y >= 0) {
+            if (res.x < len) {
+                len = res.x;
+                V3 rp = normalized(bez_gradP(b, res.y));  // bezier.h:215-224
+                n = V3(rp.y * std::sin(res.z), -rp.z, rp.y * std::cos(res.z));
+                flag = true;
+            }
+        }
+    }
+    n = n * ((dot(n, d) < 0) ? 1 : -1);
+    double newt = b.ymax - o.y;
+    if (newt > 0.1) {
+        newt = newt / d.y;
+        V3 np = o + d * newt;
+        double cz = b.cp[b.cp.size() - 1].z;
+        if ((np.x - b.position.x) * (np.x - b.position.x) + (np.z - b.position.z) * (np.z - b.position.z) <= cz * cz) {
+            len = newt;
+            n = V3(0, 1, 0);
+        }
+    }
+    return flag;
+}
+
+// ---------------------------------------------------------------- trace(), main.cpp:42-100,129-157
+struct Sink {
+    double *acc = nullptr;      // 3 doubles of the current pixel
+    uint32_t *nhit = nullptr;   // of the current pixel
+    uint64_t nrays = 0;
+    double *hp = nullptr;
+    int64_t *hp_pix = nullptr;
+    uint64_t hp_cap = 0, hp_n = 0;
+    int64_t label = 0;
+    uint64_t stats[2] = {0, 0};  // node tests, triangle tests
+};
+struct RayCtx {
+    uint64_t seed, pixel, sample;
+};
+
+static bool obj_intersect(const Scene &sc, int i, const V3 &o, const V3 &d, double &len, V3 &n, const RayCtx &rc,
+                          uint32_t path, Sink &sink) {
+    const Obj &ob = *sc.objs[i];
+    switch (ob.kind) {
+        case SPHERE: return sphere_intersect(ob, o, d, len, n);
+        case PLANE: return plane_intersect(sc, ob, o, d, len, n, sink.stats);
+        case MESH: return mesh_intersect(ob, o, d, len, n, sink.stats);
+        case BEZIER: {
+            Rng r{cgrt_key(rc.seed, rc.pixel, rc.sample, ((uint64_t)path << 16) | (uint64_t)(i + 1)), 0};
+            return bezier_intersect(ob, o, d, len, n, r);
+        }
+    }
+    return false;
+}
+
+static void trace(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int depth_left, uint32_t path,
+                  const RayCtx &rc, Sink &sink) {
+    if (depth_left <= 0) return;  // main.cpp:46
+    sink.nrays++;
+    double len = 0;
+    int id = -1;
+    V3 normalvec, temp;
+    double nearest = INF;
+    for (int i = 0; i < (int)sc.objs.size(); i++) {  // main.cpp:55-63 (strict <: first object wins ties, Q1)
+        if (obj_intersect(sc, i, org, dir, len, temp, rc, path, sink)) {
+            if (len < nearest) {
+                id = i;
+                nearest = len;
+                normalvec = temp;
+            }
+        }
+    }
+    if (id == -1) return;
+    const Obj &obj = *sc.objs[id];
+    V3 P = org + dir * nearest;
+    bool into = true;
+    V3 n_old = normalvec;
+    if (dot(normalvec, dir) > 0) {  // main.cpp:73-76
+        normalvec = -normalvec;
+        into = false;
+    }
+    V3 f = obj.color;  // getSurfaceColor: objects.h:78,466,533 ; bezier.h:299
+    if (obj.kind == PLANE && obj.tex >= 0) {
+        V3 c;
+        if (sc.textures[obj.tex]->color(P, c)) f = c;
+    }
+    if (obj.refl < EPS && obj.transp < EPS) {  // main.cpp:82-100
+        V3 hf = mul(f, adj);
+        sink.acc[0] += hf.x; sink.acc[1] += hf.y; sink.acc[2] += hf.z;
+        (*sink.nhit)++;
+        if (sink.hp && sink.hp_n < sink.hp_cap) {
+            double *o = sink.hp + 9 * sink.hp_n;
+            o[0] = hf.x; o[1] = hf.y; o[2] = hf.z;
+            o[3] = P.x; o[4] = P.y; o[5] = P.z;
+            o[6] = normalvec.x; o[7] = normalvec.y; o[8] = normalvec.z;
+            sink.hp_pix[sink.hp_n] = sink.label;
+        }
+        sink.hp_n++;
+    } else if (obj.transp < EPS) {  // mirror, main.cpp:129-134
+        V3 newdir = dir - normalvec * 2.0 * dot(normalvec, dir);
+        double refl = obj.refl;
+        V3 P2 = P + normalvec * EPS;
+        trace(sc, P2, newdir, mul(f, adj) * refl, depth_left - 1, path * 2, rc, sink);
+    } else {  // glass, main.cpp:135-157
+        double nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
+        V3 refl_dir = dir - n_old * 2.0 * dot(n_old, dir);
+        if ((cos2t = 1 - nnt * nnt * (1 - ddn * ddn)) < 0) {  // TIR keeps adj (Q3)
+            trace(sc, P + normalvec * EPS, refl_dir, adj, depth_left - 1, path * 2, rc, sink);
+            return;
+        }
+        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + std::sqrt(cos2t))));
+        double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
+        double Re = R0 + (1 - R0) * c * c * c * c * c;
+        V3 fa = mul(f, adj);
+        trace(sc, P + normalvec * EPS, refl_dir, fa * Re, depth_left - 1, path * 2, rc, sink);
+        trace(sc, P - normalvec * EPS, refr_dir, fa * (1 - Re), depth_left - 1, path * 2 + 1, rc, sink);
+    }
+}
+
+// ---------------------------------------------------------------- loaders, objects.h:338-403
+// Token-level restatement of the three scanf formats (whitespace-insensitive like scanf, Q8).
+// Malformed input stops the load (the reference would reuse stale values / loop); returns false.
+struct Tok {
+    std::vector<std::string> t;
+    size_t i = 0;
+    bool load(const char *file) {
+        FILE *f = std::fopen(file, "r");
+        if (!f) return false;
+        char buf[256];
+        while (std::fscanf(f, "%255s", buf) == 1) t.push_back(buf);
+        std::fclose(f);
+        return true;
+    }
+    bool more() const { return i < t.size(); }
+    bool lit(const char *s) {
+        if (i < t.size() && t[i] == s) { i++; return true; }
+        return false;
+    }
+    bool num(double &v) {
+        if (i >= t.size()) return false;
+        char *e;
+        v = std::strtod(t[i].c_str(), &e);
+        if (*e) return false;
+        i++;
+        return true;
+    }
+    bool integer(int &v) {
+        if (i >= t.size()) return false;
+        char *e;
+        long q = std::strtol(t[i].c_str(), &e, 10);
+        if (*e) return false;
+        v = (int)q;
+        i++;
+        return true;
+    }
+};
+static bool load_mesh(const char *file, double a, const V3 &b, int type, std::vector<Tri> &out) {
+    Tok tk;
+    if (!tk.load(file)) return true;  // missing file => freopen fails => empty mesh
+    auto xf = [&](double x, double y, double z) { return V3(x, y, -z) * a + b; };  // objects.h:348,365,384
+    if (type == 0) {
+        while (tk.more()) {
+            double v[9];
+            if (!tk.lit("begin")) return false;
+            for (int k = 0; k < 3; k++) {
+                if (!tk.lit("vertex")) return false;
+                for (int c = 0; c < 3; c++) if (!tk.num(v[3 * k + c])) return false;
+            }
+            if (!tk.lit("end")) return false;
+            out.push_back(Tri{xf(v[0], v[1], v[2]), xf(v[3], v[4], v[5]), xf(v[6], v[7], v[8])});
+        }
+        return true;
+    }
+    int num;
+    if (!tk.integer(num)) return false;
+    std::vector<V3> verts;
+    for (int i = 0; i < num; i++) {
+        double x, y, z;
+        if (!tk.lit("v") || !tk.num(x) || !tk.num(y) || !tk.num(z)) return false;
+        verts.push_back(V3(x, y, -z));
+    }
+    if (type == 2) {  // optional vn / vt blocks (objects.h:387-392)
+        while (tk.lit("vn")) { double q; tk.num(q); tk.num(q); tk.num(q); }
+        while (tk.lit("vt")) { double q; tk.num(q); tk.num(q); }
+    }
+    if (!tk.integer(num)) return false;
+    for (int i = 0; i < num; i++) {
+        int id[3];
+        if (!tk.lit("f")) return false;
+        for (int k = 0; k < 3; k++) {
+            if (type == 1) {
+                if (!tk.integer(id[k])) return false;
+            } else {
+                if (!tk.more()) return false;
+                id[k] = std::atoi(tk.t[tk.i++].c_str());  // "a/b/c": leading integer
+            }
+            if (id[k] < 1 || id[k] > (int)verts.size()) return false;
+        }
+        out.push_back(Tri{verts[id[0] - 1] * a + b, verts[id[1] - 1] * a + b, verts[id[2] - 1] * a + b});
+    }
+    return true;
+}
+
+}  // namespace orc
+
+using namespace orc;
+static V3 v3(const double *p) { return V3(p[0], p[1], p[2]); }
+static int g_threads = 1;
+
+extern "C" {
+
+uint64_t orc_debug_jitter_events(void) { return orc::g_jitter_events; }
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void *orc_scene_new(void) { return new Scene(); }
+void orc_scene_free(void *p) { delete (Scene *)p; }
+
+int orc_add_sphere(void *sp, const double *c, double r, const double *col, double refl, double transp) {
+    Scene *s = (Scene *)sp;
+    Obj *o = new Obj();
+    o->kind = SPHERE; o->center = v3(c); o->radius = r; o->radius2 = r * r;  // objects.h:35
+    o->color = v3(col); o->refl = refl; o->transp = transp;
+    s->objs.push_back(o);
+    return (int)s->objs.size() - 1;
+}
+int orc_add_texture(void *sp, const uint8_t *rgb, int rows, int cols, const double *n, const double *p, double lx,
+                    double ly, int bump) {
+    Scene *s = (Scene *)sp;
+    Texture *t = new Texture();
+    t->rows = rows; t->cols = cols;
+    t->rgb.assign(rgb, rgb + (size_t)rows * cols * 3);
+    t->normal = v3(n); t->position = v3(p); t->lenx = lx; t->leny = ly; t->isbump = bump != 0;
+    t->make_height();
+    s->textures.push_back(t);
+    return (int)s->textures.size() - 1;
+}
+int orc_add_plane(void *sp, const double *p, const double *n, const double *col, double refl, double transp,
+                  int tex_id) {
+    Scene *s = (Scene *)sp;
+    Obj *o = new Obj();
+    o->kind = PLANE; o->position = v3(p); o->normal = v3(n); o->color = v3(col);
+    o->refl = refl; o->transp = transp; o->tex = tex_id;
+    if (tex_id >= 0) {
+        const Texture &tx = *s->textures[tex_id];
+        if (std::fabs(o->normal.y - 1.0) < 1e-5 && tx.isbump) {  // objects.h:482-503 (Q10)
+            const int step = 3;
+            const int R = tx.rows, C = tx.cols;
+            for (int i = 0; i < R / step - 1; i++)
+                for (int j = 0; j < C / step - 1; j++) {
+                    double x1 = tx.position.x + tx.lenx * j * step / C;
+                    double x2 = tx.position.x + tx.lenx * (j + 1) * step / C;
+                    double y1 = tx.position.z + tx.leny * i * step / R;
+                    double y2 = tx.position.z + tx.leny * (i + 1) * step / R;
+                    auto H = [&](int a, int b) { return tx.height[(size_t)a * C + b]; };
+                    V3 a(x1, H(i * step, j * step) + o->position.y, y1);
+                    V3 b(x2, H(i * step, (j + 1) * step) + o->position.y, y1);
+                    V3 c(x1, H((i + 1) * step, j * step) + o->position.y, y2);
+                    V3 d(x2, H((i + 1) * step, (j + 1) * step) + o->position.y, y2);
+                    o->bump.tris.push_back(Tri{a, b, c});
+                    o->bump.tris.push_back(Tri{d, b, c});
+                }
+            o->bump.build_all();
+            o->has_bump_tree = true;
+        }
+    }
+    s->plane_ids.push_back((int)s->objs.size());
+    s->objs.push_back(o);
+    return (int)s->objs.size() - 1;
+}
+static int add_mesh(Scene *s, std::vector<Tri> &tris, const double *col, double refl, double transp, int type) {
+    Obj *o = new Obj();
+    o->kind = MESH; o->color = v3(col); o->refl = refl; o->transp = transp; o->objtype = type;
+    o->tree.tris.swap(tris);
+    o->tree.build_all();
+    s->mesh_ids.push_back((int)s->objs.size());
+    s->objs.push_back(o);
+    return (int)s->objs.size() - 1;
+}
+int orc_add_mesh_file(void *sp, const char *file, double a, const double *b, const double *col, double refl,
+                      double transp, int typeofdata) {
+    std::vector<Tri> tris;
+    if (!load_mesh(file, a, v3(b), typeofdata, tris)) return -1;
+    return add_mesh((Scene *)sp, tris, col, refl, transp, typeofdata);
+}
+int orc_add_mesh_tris(void *sp, const double *tri, int ntri, const double *col, double refl, double transp,
+                      int typeofdata) {
+    std::vector<Tri> tris;
+    for (int i = 0; i < ntri; i++) tris.push_back(Tri{v3(tri + 9 * i), v3(tri + 9 * i + 3), v3(tri + 9 * i + 6)});
+    return add_mesh((Scene *)sp, tris, col, refl, transp, typeofdata);
+}
+int orc_add_bezier(void *sp, const double *cp, int ncp, const double *pos, const double *col, double refl,
+                   double transp) {
+    Scene *s = (Scene *)sp;
+    Obj *o = new Obj();
+    o->kind = BEZIER; o->color = v3(col); o->refl = refl; o->transp = transp; o->position = v3(pos);
+    for (int i = 0; i < ncp; i++) o->cp.push_back(v3(cp + 3 * i));
+    double max_z = -INF, max_y = -INF, min_y = INF;  // bezier.h:50-69
+    for (auto &c : o->cp) {
+        if (c.z > max_z) max_z = c.z;
+        if (c.y > max_y) max_y = c.y;
+        if (c.y < min_y) min_y = c.y;
+    }
+    o->xmax = max_z + o->position.x; o->xmin = -max_z + o->position.x;
+    o->ymax = max_y + o->position.y; o->ymin = min_y + o->position.y;
+    o->zmax = max_z + o->position.z; o->zmin = -max_z + o->position.z;
+    s->objs.push_back(o);
+    return (int)s->objs.size() - 1;
+}
+
+// ---- introspection (same shapes as the ref_* functions) ----
+static const Tree *pick_tree(void *sp, int kind, int idx) {
+    Scene *s = (Scene *)sp;
+    return kind == 0 ? &s->objs[s->mesh_ids[idx]]->tree : &s->objs[s->plane_ids[idx]]->bump;
+}
+int orc_mesh_ntris(void *sp, int mesh) { return (int)pick_tree(sp, 0, mesh)->tris.size(); }
+static void dump_tris(const Tree &t, double *out) {
+    for (size_t i = 0; i < t.tris.size(); i++) {
+        const Tri &q = t.tris[i];
+        double *o = out + 9 * i;
+        o[0] = q.pa.x; o[1] = q.pa.y; o[2] = q.pa.z; o[3] = q.pb.x; o[4] = q.pb.y; o[5] = q.pb.z;
+        o[6] = q.pc.x; o[7] = q.pc.y; o[8] = q.pc.z;
+    }
+}
+void orc_mesh_tris(void *sp, int mesh, double *out) { dump_tris(*pick_tree(sp, 0, mesh), out); }
+int orc_tree_nnodes(void *sp, int kind, int idx) { return (int)pick_tree(sp, kind, idx)->nodes.size(); }
+int orc_tree_nleaftris(void *sp, int kind, int idx) {
+    const Tree &t = *pick_tree(sp, kind, idx);
+    size_t k = 0;
+    for (auto &n : t.nodes) if ((int)n.ids.size() < MINKD) k += n.ids.size();
+    return (int)k;
+}
+void orc_tree_dump(void *sp, int kind, int idx, int32_t *node_lr_size, int32_t *leaf_ids, double *bbox) {
+    const Tree &t = *pick_tree(sp, kind, idx);
+    size_t k = 0;
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        const Node &nd = t.nodes[i];
+        if (node_lr_size) {
+            node_lr_size[3 * i] = nd.left; node_lr_size[3 * i + 1] = nd.right; node_lr_size[3 * i + 2] = (int32_t)nd.ids.size();
+        }
+        if (bbox) {
+            bbox[6 * i] = nd.xmin; bbox[6 * i + 1] = nd.xmax; bbox[6 * i + 2] = nd.ymin;
+            bbox[6 * i + 3] = nd.ymax; bbox[6 * i + 4] = nd.zmin; bbox[6 * i + 5] = nd.zmax;
+        }
+        if ((int)nd.ids.size() < MINKD && leaf_ids) for (int id : nd.ids) leaf_ids[k++] = id;
+    }
+}
+int orc_plane_bump_ntris(void *sp, int idx) { return (int)pick_tree(sp, 1, idx)->tris.size(); }
+void orc_plane_bump_tris(void *sp, int idx, double *out) { dump_tris(*pick_tree(sp, 1, idx), out); }
+
+// ---- function-level probes ----
+void orc_intersect_batch(void *sp, int obj, const double *org, const double *dir, const uint64_t *keys, int n,
+                         int32_t *hit, double *len, double *normal) {
+    Scene *s = (Scene *)sp;
+    for (int i = 0; i < n; i++) {
+        const Obj &ob = *s->objs[obj];
+        double l = 0;
+        V3 nv;
+        bool h = false;
+        V3 o = v3(org + 3 * i), d = v3(dir + 3 * i);
+        switch (ob.kind) {
+            case SPHERE: h = sphere_intersect(ob, o, d, l, nv); break;
+            case PLANE: h = plane_intersect(*s, ob, o, d, l, nv, nullptr); break;
+            case MESH: h = mesh_intersect(ob, o, d, l, nv, nullptr); break;
+            case BEZIER: { Rng r{keys ? keys[i] : 0, 0}; h = bezier_intersect(ob, o, d, l, nv, r); } break;
+        }
+        hit[i] = h ? 1 : 0;
+        len[i] = l;
+        normal[3 * i] = nv.x; normal[3 * i + 1] = nv.y; normal[3 * i + 2] = nv.z;
+    }
+}
+void orc_surface_color_batch(void *sp, int obj, const double *pts, int n, double *out) {
+    Scene *s = (Scene *)sp;
+    const Obj &ob = *s->objs[obj];
+    for (int i = 0; i < n; i++) {
+        V3 f = ob.color, c;
+        if (ob.kind == PLANE && ob.tex >= 0 && s->textures[ob.tex]->color(v3(pts + 3 * i), c)) f = c;
+        out[3 * i] = f.x; out[3 * i + 1] = f.y; out[3 * i + 2] = f.z;
+    }
+}
+void orc_lens_samples(uint64_t seed, const int64_t *pix, const int32_t *smp, int n, double radius, double *out) {
+    for (int i = 0; i < n; i++) {
+        Rng r{cgrt_key(seed, (uint64_t)pix[i], (uint64_t)smp[i], 0), 0};
+        V3 v = lens_sample(r, radius);
+        out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+    }
+}
+
+// ---- the eye pass (main.cpp:185-219).  Same signature as ref_trace_grid; `hashsize` is ignored.
+// stats (optional, 2 x uint64): node tests, triangle tests.  Hitpoint capture forces one thread.
+double orc_trace_grid(void *sp, const orc_camera *cam, const orc_grid *g, int hashsize, double *acc, uint32_t *nhit,
+                      uint64_t *nrays, double *hp, int64_t *hp_pix, uint64_t hp_cap, uint64_t *hp_count) {
+    (void)hashsize;
+    Scene *s = (Scene *)sp;
+    const int W = g->W, H = g->H;
+    V3 camorg = v3(cam->cam);
+    uint64_t total_rays = 0, total_hp = 0;
+    int threads = hp ? 1 : g_threads;
+    auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : total_rays, total_hp)
+    for (int h = g->row0; h < g->row0 + g->nrows; h++) {
+        Sink sink;
+        sink.hp = hp; sink.hp_pix = hp_pix; sink.hp_cap = hp_cap;
+        if (hp) sink.hp_n = total_hp;  // single-threaded in this mode
+        for (int w = 0; w < W; w++) {
+            size_t pix = (size_t)(h - g->row0) * W + w;
+            double x = (2.0 * ((double)w / W) - 1) * cam->half_width;               // main.cpp:188
+            double y = (2.0 * ((double)h / H) - 1) * cam->half_width * H / W;       // main.cpp:189
+            V3 dir = normalized(V3(x, y, 0) - camorg);                               // main.cpp:198
+            V3 pof = dir * ((cam->focus_plane - camorg.z) / dir.z) + camorg;         // main.cpp:203
+            sink.acc = acc + 3 * pix;
+            sink.nhit = nhit + pix;
+            for (int j = g->sample0; j < g->sample0 + g->spp; j++) {
+                RayCtx rc{g->seed, (uint64_t)h * (uint64_t)W + (uint64_t)w, (uint64_t)j};
+                sink.label = ((int64_t)(j - g->sample0) << 32) | (int64_t)pix;
+                if (cam->lens_radius > 0) {
+                    Rng r{cgrt_key(rc.seed, rc.pixel, rc.sample, 0), 0};
+                    V3 neworg = camorg + lens_sample(r, cam->lens_radius);           // main.cpp:205
+                    V3 newdir = normalized(pof - neworg);                            // main.cpp:206
+                    trace(*s, neworg, newdir, V3(1, 1, 1), g->depth, 1, rc, sink);  // main.cpp:207
+                } else {
+                    trace(*s, camorg, dir, V3(1, 1, 1), g->depth, 1, rc, sink);     // main.cpp:209
+                }
+            }
+        }
+        total_rays += sink.nrays;
+        if (hp) total_hp = sink.hp_n; else total_hp += sink.hp_n;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (nrays) *nrays = total_rays;
+    if (hp_count) *hp_count = total_hp;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"
