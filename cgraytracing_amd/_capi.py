@@ -1,0 +1,94 @@
+"""ctypes binding of libcgrt.so (include/cgrt.h).  There is no fallback: if the HIP library has not been
+built (``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C cgraytracing_amd/csrc``) importing
+this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcgrt.so")
+
+CGRT_OK = 0
+CGRT_NCOUNTERS = 8
+CNT_RAYS, CNT_HITPOINTS, CNT_WAVE_ITERS, CNT_NODE_TESTS, CNT_TRI_TESTS = 0, 1, 2, 3, 4
+
+
+class CgrtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libcgrt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Camera(C.Structure):
+    _fields_ = [("cam", C.c_double * 3), ("half_width", C.c_double), ("focus_plane", C.c_double),
+                ("lens_radius", C.c_double)]
+
+
+class Grid(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rows", C.c_int32), ("row_offset", C.c_int32),
+                ("stripe_rows", C.c_int32), ("stripe_rank", C.c_int32), ("stripe_nranks", C.c_int32),
+                ("spp", C.c_int32), ("sample_offset", C.c_int32), ("spp_total", C.c_int32),
+                ("max_depth", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64)]
+
+
+class SceneStats(C.Structure):
+    _fields_ = [("n_objects", C.c_int32), ("n_spheres", C.c_int32), ("n_planes", C.c_int32),
+                ("n_meshes", C.c_int32), ("n_beziers", C.c_int32), ("n_textures", C.c_int32),
+                ("n_trees", C.c_int32), ("committed", C.c_int32), ("n_triangles", C.c_int64),
+                ("n_nodes", C.c_int64), ("device_bytes", C.c_int64), ("scene_bytes_fp64", C.c_int64)]
+
+
+# every symbol include/cgrt.h declares, with its signature
+_DP = C.POINTER(C.c_double)
+SIGNATURES = {
+    "cgrt_version": (C.c_int, []),
+    "cgrt_last_error": (C.c_char_p, []),
+    "cgrt_scene_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "cgrt_scene_destroy": (None, [C.c_void_p]),
+    "cgrt_scene_add_sphere": (C.c_int, [C.c_void_p, _DP, C.c_double, _DP, C.c_double, C.c_double]),
+    "cgrt_scene_add_texture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _DP, _DP, C.c_double,
+                                         C.c_double, C.c_int]),
+    "cgrt_scene_add_plane": (C.c_int, [C.c_void_p, _DP, _DP, _DP, C.c_double, C.c_double, C.c_int]),
+    "cgrt_scene_add_mesh_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, _DP, _DP, C.c_double, C.c_double,
+                                           C.c_int]),
+    "cgrt_scene_add_mesh_triangles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _DP, C.c_double, C.c_double,
+                                                C.c_int]),
+    "cgrt_scene_add_bezier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _DP, _DP, C.c_double, C.c_double]),
+    "cgrt_scene_commit": (C.c_int, [C.c_void_p, C.c_int]),
+    "cgrt_scene_get_stats": (C.c_int, [C.c_void_p, C.POINTER(SceneStats)]),
+    "cgrt_scene_tree_sizes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]),
+    "cgrt_scene_tree_dump": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cgrt_trace_grid": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "cgrt_trace_grid_host": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "cgrt_intersect_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if libcgrt.so is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "cgraytracing_amd: %s not found -- build the HIP library first "
+                "(make -C cgraytracing_amd/csrc, or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise CgrtError(rc, lib().cgrt_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,354 @@
+// Host-side scene assembly for libcgrt.so (see cgrt_build.h).  Citations: /root/reference/<file>:<line>.
+#include "cgrt_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace cgrt {
+
+namespace {
+
+inline double hi3(double a, double b, double c) { return (a > b && a > c) ? a : (b > c ? b : c); }  // util.h:16-27
+inline double lo3(double a, double b, double c) { return (a < b && a < c) ? a : (b < c ? b : c); }  // util.h:33-42
+
+// ---- tree build -------------------------------------------------------------------------------
+// The reference builds an object-median tree (it calls it a KD-tree): every node takes the triangle
+// list it was handed, records its bounding box, and -- when it holds 10 or more triangles -- sorts
+// the list by the per-triangle MAXIMUM coordinate on axis depth%3 with std::sort, gives the lower
+// half (n/2) to the left child and the rest to the right (objects.h:217-267).  Nodes are numbered
+// in the order they are created, which is preorder.
+//
+// Which side of a glass mesh a ray is on is decided by the parity of a counter that depends on the
+// order of triangles inside the leaves (objects.h:281-286,321-327), so the leaf order -- including
+// how std::sort happens to arrange equal keys -- is part of the observable behaviour.  We therefore
+// run the same std::sort over the same sequence: sorting a slice of one id array in place visits
+// the same comparisons as sorting the reference's private copy of that slice.
+struct Builder {
+    const std::vector<double> &T;  // 9 doubles per triangle
+    std::vector<int32_t> ids;
+    HostTree &out;
+
+    double key(int32_t id, int axis) const {
+        const double *t = &T[9 * (size_t)id];
+        return hi3(t[axis], t[3 + axis], t[6 + axis]);
+    }
+    void emit(size_t b, size_t e, int axis) {
+        const int32_t me = (int32_t)out.nodes.size();
+        const size_t n = e - b;
+        double mx[3] = {-kInf, -kInf, -kInf}, mn[3] = {kInf, kInf, kInf};  // objects.h:227-232
+        for (size_t i = b; i < e; i++) {
+            const double *t = &T[9 * (size_t)ids[i]];
+            for (int k = 0; k < 3; k++) {
+                double h = hi3(t[k], t[3 + k], t[6 + k]), l = lo3(t[k], t[3 + k], t[6 + k]);
+                if (mx[k] < h) mx[k] = h;
+                if (mn[k] > l) mn[k] = l;
+            }
+        }
+        NodeRec nr;
+        for (int k = 0; k < 3; k++) {
+            nr.lo[k] = mn[k] - kBoxPad;
+            nr.hi[k] = mx[k] + kBoxPad;
+        }
+        nr.skip = 0;
+        nr.tri_begin = 0;
+        nr.tri_count = -1;
+        nr.pad = 0;
+        out.nodes.push_back(nr);
+        out.node_lr_size.push_back(-1);
+        out.node_lr_size.push_back(-1);
+        out.node_lr_size.push_back((int32_t)n);
+        for (int k = 0; k < 3; k++) {
+            out.bbox.push_back(mn[k]);
+            out.bbox.push_back(mx[k]);
+        }
+        if ((int)n < kMinKd) {  // leaf (objects.h:251, 273)
+            out.nodes[me].tri_begin = (int32_t)out.tris.size();
+            out.nodes[me].tri_count = (int32_t)n;
+            for (size_t i = b; i < e; i++) {
+                const double *t = &T[9 * (size_t)ids[i]];
+                TriRec tr;
+                for (int k = 0; k < 3; k++) {
+                    tr.pa[k] = t[k];
+                    tr.e1[k] = t[k] - t[3 + k];  // pa - pb (objects.h:98)
+                    tr.e2[k] = t[k] - t[6 + k];  // pa - pc (objects.h:99)
+                }
+                out.tris.push_back(tr);
+                out.leaf_ids.push_back(ids[i]);
+            }
+            out.nodes[me].skip = me + 1;
+            return;
+        }
+        std::sort(ids.begin() + b, ids.begin() + e,
+                  [this, axis](int32_t p, int32_t q) { return key(p, axis) < key(q, axis); });
+        const size_t mid = b + n / 2;
+        const int next_axis = (axis + 1) % 3;
+        out.node_lr_size[3 * (size_t)me + 0] = (int32_t)out.nodes.size();
+        emit(b, mid, next_axis);
+        out.node_lr_size[3 * (size_t)me + 1] = (int32_t)out.nodes.size();
+        emit(mid, e, next_axis);
+        out.nodes[me].skip = (int32_t)out.nodes.size();
+    }
+};
+
+void set3(double *d, const double *s) {
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+}
+
+ObjRec blank_obj(int kind, const double sc[3], double refl, double transp) {
+    ObjRec o;
+    std::memset(&o, 0, sizeof(o));
+    o.kind = kind;
+    set3(o.col, sc);
+    o.refl = refl;
+    o.transp = transp;
+    o.tree = -1;
+    o.tex = -1;
+    return o;
+}
+
+// ---- text scanning for the three mesh formats (objects.h:343-400) ------------------------------
+struct Scanner {
+    std::vector<char> buf;
+    const char *p = nullptr, *end = nullptr;
+    bool open(const char *file) {
+        FILE *f = std::fopen(file, "rb");
+        if (!f) return false;
+        std::fseek(f, 0, SEEK_END);
+        long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        buf.resize((size_t)(n > 0 ? n : 0) + 1);
+        size_t got = n > 0 ? std::fread(buf.data(), 1, (size_t)n, f) : 0;
+        std::fclose(f);
+        buf[got] = 0;
+        p = buf.data();
+        end = p + got;
+        return true;
+    }
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v')) p++;
+    }
+    bool at_end() {
+        ws();
+        return p >= end;
+    }
+    bool word(const char *w) {  // literal token followed by whitespace/end
+        ws();
+        size_t n = std::strlen(w);
+        if ((size_t)(end - p) < n || std::strncmp(p, w, n) != 0) return false;
+        const char *q = p + n;
+        if (q < end && !(*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r')) return false;
+        p = q;
+        return true;
+    }
+    bool real(double &v) {
+        ws();
+        char *e = nullptr;
+        v = std::strtod(p, &e);
+        if (e == p) return false;
+        p = e;
+        return true;
+    }
+    bool integer(long &v) {
+        ws();
+        char *e = nullptr;
+        v = std::strtol(p, &e, 10);
+        if (e == p) return false;
+        p = e;
+        return true;
+    }
+    void skip_token() {
+        ws();
+        while (p < end && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+    }
+};
+
+}  // namespace
+
+void HostTree::build() {
+    nodes.clear();
+    tris.clear();
+    node_lr_size.clear();
+    bbox.clear();
+    leaf_ids.clear();
+    Builder b{tri9, {}, *this};
+    const size_t n = tri9.size() / 9;
+    b.ids.resize(n);
+    for (size_t i = 0; i < n; i++) b.ids[i] = (int32_t)i;
+    b.emit(0, n, 0);
+}
+
+bool load_mesh_file(const char *file, double a, const double b[3], int type, std::vector<double> &tri9,
+                    std::string &err) {
+    tri9.clear();
+    Scanner sc;
+    if (!sc.open(file)) return true;  // freopen() fails silently in the reference => empty mesh
+    auto put = [&](const double *v) {  // (x, y, -z) * a + b   (objects.h:348,365,384)
+        tri9.push_back(v[0] * a + b[0]);
+        tri9.push_back(v[1] * a + b[1]);
+        tri9.push_back(-v[2] * a + b[2]);
+    };
+    if (type == 0) {  // begin / vertex x y z (x3) / end   (objects.h:346)
+        while (!sc.at_end()) {
+            double v[9];
+            if (!sc.word("begin")) { err = "type-0 mesh: expected 'begin'"; return false; }
+            for (int k = 0; k < 3; k++) {
+                if (!sc.word("vertex")) { err = "type-0 mesh: expected 'vertex'"; return false; }
+                for (int c = 0; c < 3; c++)
+                    if (!sc.real(v[3 * k + c])) { err = "type-0 mesh: bad coordinate"; return false; }
+            }
+            if (!sc.word("end")) { err = "type-0 mesh: expected 'end'"; return false; }
+            put(v); put(v + 3); put(v + 6);
+        }
+        return true;
+    }
+    if (type != 1 && type != 2) { err = "unknown typeofdata"; return false; }
+    long nv = 0, nf = 0;
+    if (!sc.integer(nv) || nv < 0) { err = "mesh: bad vertex count"; return false; }
+    std::vector<double> verts((size_t)nv * 3);
+    for (long i = 0; i < nv; i++) {
+        if (!sc.word("v")) { err = "mesh: expected 'v'"; return false; }
+        for (int c = 0; c < 3; c++)
+            if (!sc.real(verts[3 * (size_t)i + c])) { err = "mesh: bad vertex"; return false; }
+    }
+    if (type == 2) {  // optional vn / vt records (objects.h:387-392)
+        double q;
+        while (sc.word("vn")) { if (!sc.real(q) || !sc.real(q) || !sc.real(q)) { err = "mesh: bad vn"; return false; } }
+        while (sc.word("vt")) { if (!sc.real(q) || !sc.real(q)) { err = "mesh: bad vt"; return false; } }
+    }
+    if (!sc.integer(nf) || nf < 0) { err = "mesh: bad face count"; return false; }
+    for (long i = 0; i < nf; i++) {
+        if (!sc.word("f")) { err = "mesh: expected 'f'"; return false; }
+        long id[3];
+        for (int k = 0; k < 3; k++) {
+            if (!sc.integer(id[k])) { err = "mesh: bad face index"; return false; }
+            if (type == 2) sc.skip_token();  // the "/b/c" tail of "a/b/c" (objects.h:397)
+            if (id[k] < 1 || id[k] > nv) { err = "mesh: face index out of range"; return false; }
+        }
+        for (int k = 0; k < 3; k++) put(&verts[3 * (size_t)(id[k] - 1)]);
+    }
+    return true;
+}
+
+int HostScene::add_sphere(const double c[3], double r, const double sc[3], double refl, double transp) {
+    ObjRec o = blank_obj(KIND_SPHERE, sc, refl, transp);
+    set3(o.a, c);
+    o.s0 = r * r;  // radius2(r * r), objects.h:35
+    objs.push_back(o);
+    return (int)objs.size() - 1;
+}
+
+int HostScene::add_texture(const uint8_t *rgb, int rows, int cols, const double n[3], const double p[3], double lx,
+                           double ly, int isbump) {
+    if (!rgb || rows <= 0 || cols <= 0) { error = "texture: empty image"; return -1; }
+    HostTexture t;
+    t.rgb.assign(rgb, rgb + (size_t)rows * cols * 3);
+    t.rows = rows;
+    t.cols = cols;
+    set3(t.n, n);
+    set3(t.p, p);
+    t.lenx = lx;
+    t.leny = ly;
+    t.isbump = isbump != 0;
+    textures.push_back(std::move(t));
+    return (int)textures.size() - 1;
+}
+
+int HostScene::add_plane(const double p[3], const double n[3], const double sc[3], double refl, double transp,
+                         int tex) {
+    if (tex >= (int)textures.size()) { error = "plane: unknown texture id"; return -1; }
+    ObjRec o = blank_obj(KIND_PLANE, sc, refl, transp);
+    set3(o.a, p);
+    set3(o.b, n);
+    o.tex = tex < 0 ? -1 : tex;
+    if (tex >= 0 && textures[tex].isbump && std::fabs(n[1] - 1.0) < 1e-5) {
+        // Displacement mesh of a bump-mapped floor (objects.h:482-503): one quad per 3x3 texel block,
+        // split into triangles (a,b,c) and (d,b,c); heights 0.5*(1-exp(-3.3*luma)) (texture.h:28-35).
+        const HostTexture &tx = textures[tex];
+        const int R = tx.rows, C = tx.cols, step = 3;
+        std::vector<double> height((size_t)R * C);
+        for (int i = 0; i < R; i++)
+            for (int j = 0; j < C; j++) {
+                const uint8_t *q = &tx.rgb[3 * ((size_t)i * C + j)];
+                double luma = (0.299 * ((double)q[0] / 256.0) + 0.587 * ((double)q[1] / 256.0) +
+                               0.114 * ((double)q[2] / 256.0));
+                double h = 1 - std::exp(-3.3 * luma);
+                height[(size_t)i * C + j] = h * 0.5;
+            }
+        HostTree tree;
+        for (int i = 0; i < R / step - 1; i++)
+            for (int j = 0; j < C / step - 1; j++) {
+                const double x1 = tx.p[0] + tx.lenx * j * step / C;
+                const double x2 = tx.p[0] + tx.lenx * (j + 1) * step / C;
+                const double z1 = tx.p[2] + tx.leny * i * step / R;
+                const double z2 = tx.p[2] + tx.leny * (i + 1) * step / R;
+                const double ya = height[(size_t)(i * step) * C + j * step] + p[1];
+                const double yb = height[(size_t)(i * step) * C + (j + 1) * step] + p[1];
+                const double yc = height[(size_t)((i + 1) * step) * C + j * step] + p[1];
+                const double yd = height[(size_t)((i + 1) * step) * C + (j + 1) * step] + p[1];
+                const double A[3] = {x1, ya, z1}, B[3] = {x2, yb, z1}, Cc[3] = {x1, yc, z2}, D[3] = {x2, yd, z2};
+                for (const double *v : {A, B, Cc}) tree.tri9.insert(tree.tri9.end(), v, v + 3);
+                for (const double *v : {D, B, Cc}) tree.tri9.insert(tree.tri9.end(), v, v + 3);
+            }
+        tree.build();
+        trees.push_back(std::move(tree));
+        o.tree = (int)trees.size() - 1;
+    }
+    objs.push_back(o);
+    return (int)objs.size() - 1;
+}
+
+int HostScene::add_mesh_triangles(const double *tri9, int ntri, const double sc[3], double refl, double transp,
+                                  int type) {
+    if (ntri < 0 || (ntri > 0 && !tri9)) { error = "mesh: bad triangle array"; return -1; }
+    ObjRec o = blank_obj(KIND_MESH, sc, refl, transp);
+    o.aux = type;
+    HostTree tree;
+    tree.tri9.assign(tri9, tri9 + (size_t)ntri * 9);
+    tree.build();  // objects.h:402
+    trees.push_back(std::move(tree));
+    o.tree = (int)trees.size() - 1;
+    objs.push_back(o);
+    return (int)objs.size() - 1;
+}
+
+int HostScene::add_mesh_file(const char *file, double a, const double b[3], const double sc[3], double refl,
+                             double transp, int type) {
+    std::vector<double> t9;
+    if (!file || !load_mesh_file(file, a, b, type, t9, error)) return -2;
+    return add_mesh_triangles(t9.data(), (int)(t9.size() / 9), sc, refl, transp, type);
+}
+
+int HostScene::add_bezier(const double *cp3, int ncp, const double pos[3], const double sc[3], double refl,
+                          double transp) {
+    if (!cp3 || ncp < 1 || ncp > 6) { error = "bezier: 1..6 control points"; return -1; }  // bezier.h:46
+    ObjRec o = blank_obj(KIND_BEZIER, sc, refl, transp);
+    set3(o.a, pos);
+    BezierRec b;
+    std::memset(&b, 0, sizeof(b));
+    b.ncp = ncp;
+    double max_z = -kInf, max_y = -kInf, min_y = kInf;  // bezier.h:50-63
+    for (int i = 0; i < ncp; i++) {
+        for (int k = 0; k < 3; k++) b.cp[i][k] = cp3[3 * i + k];
+        if (b.cp[i][2] > max_z) max_z = b.cp[i][2];
+        if (b.cp[i][1] > max_y) max_y = b.cp[i][1];
+        if (b.cp[i][1] < min_y) min_y = b.cp[i][1];
+    }
+    b.box[0] = -max_z + pos[0];  // xmin
+    b.box[1] = max_z + pos[0];   // xmax
+    b.box[2] = min_y + pos[1];
+    b.box[3] = max_y + pos[1];
+    b.box[4] = -max_z + pos[2];
+    b.box[5] = max_z + pos[2];
+    o.b[0] = b.cp[ncp - 1][2];  // radius of the cap disc (bezier.h:277)
+    beziers.push_back(b);
+    o.aux = (int)beziers.size() - 1;
+    objs.push_back(o);
+    return (int)objs.size() - 1;
+}
+
+}  // namespace cgrt

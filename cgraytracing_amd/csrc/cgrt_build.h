@@ -1,0 +1,55 @@
+// Host-side scene assembly: mesh loaders, bump-mesh construction, tree build, flattening.
+// These are the reference's pre-pass (objects.h:217-267,338-403,480-504; texture.h:19-38), run once per
+// scene on the CPU; the per-ray work is all in cgrt_hip.hip.
+#ifndef CGRT_BUILD_H
+#define CGRT_BUILD_H
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "cgrt_types.h"
+
+namespace cgrt {
+
+struct HostTree {
+    std::vector<double> tri9;        // construction order, 9 doubles per triangle
+    // reference-numbered view (for verification dumps)
+    std::vector<int32_t> node_lr_size;  // left, right, count
+    std::vector<double> bbox;           // xmin,xmax,ymin,ymax,zmin,zmax (unpadded)
+    std::vector<int32_t> leaf_ids;      // triangle ids of leaves, node order
+    // device view
+    std::vector<NodeRec> nodes;
+    std::vector<TriRec> tris;
+    void build();
+};
+
+struct HostTexture {
+    std::vector<uint8_t> rgb;
+    int rows = 0, cols = 0;
+    double n[3], p[3], lenx = 0, leny = 0;
+    bool isbump = false;
+};
+
+struct HostScene {
+    std::vector<ObjRec> objs;
+    std::vector<HostTree> trees;
+    std::vector<HostTexture> textures;
+    std::vector<BezierRec> beziers;
+    std::string error;
+
+    int add_sphere(const double c[3], double r, const double sc[3], double refl, double transp);
+    int add_texture(const uint8_t *rgb, int rows, int cols, const double n[3], const double p[3], double lx,
+                    double ly, int isbump);
+    int add_plane(const double p[3], const double n[3], const double sc[3], double refl, double transp, int tex);
+    int add_mesh_file(const char *file, double a, const double b[3], const double sc[3], double refl,
+                      double transp, int type);
+    int add_mesh_triangles(const double *tri9, int ntri, const double sc[3], double refl, double transp, int type);
+    int add_bezier(const double *cp3, int ncp, const double pos[3], const double sc[3], double refl, double transp);
+};
+
+// returns false and sets err on malformed input; a missing file gives an empty list and true
+bool load_mesh_file(const char *file, double a, const double b[3], int type, std::vector<double> &tri9,
+                    std::string &err);
+
+}  // namespace cgrt
+#endif

@@ -1,0 +1,877 @@
+// libcgrt.so -- gfx950 (MI355X, CDNA4) kernels and the C ABI of include/cgrt.h.
+//
+// One kernel, trace_grid_kernel, replaces the reference's serial pixel/sample loop (main.cpp:185-219) and
+// the recursive trace() under it (main.cpp:42-100,129-157):
+//   * a workgroup = 4 wavefronts = a 32x8 pixel tile; each wave owns a 16x4 sub-tile, one pixel per lane;
+//   * the top-level object list (`objs`, main.cpp:277) is staged once per workgroup in LDS and walked by all
+//     64 lanes in lockstep (kind is wave-uniform, so the type dispatch is a scalar branch, not a virtual call);
+//   * recursion is an explicit per-lane stack of pending refracted rays (<= 4 entries: depth budget 5) and a
+//     lane that finishes a sample's ray tree immediately starts its next sample (persistent-lane loop);
+//   * all geometry is fp64 with FMA contraction disabled, so hit decisions are the reference's decisions;
+//   * the per-pixel accumulator is summed in fp64 in the reference's own order, scaled by 1/spp, rounded once
+//     to fp32 and written through an LDS transpose as 384-byte contiguous row segments.
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cgrt.h"
+#include "cgrt_build.h"
+#include "cgrt_rng.hpp"
+#include "cgrt_types.h"
+
+using namespace cgrt;
+
+// =====================================================================================================
+// device math: the reference's Vec3 (vec3.h:11-119), same operation order, no contraction
+// =====================================================================================================
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double f) { return mk(a.x * f, a.y * f, a.z * f); }
+__device__ __forceinline__ V3 mulv(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// vec3.h:36-44
+__device__ __forceinline__ V3 normalized(V3 a) {
+    double len = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (len > 0) {
+        double r = 1 / len;
+        a.x *= r;
+        a.y *= r;
+        a.z *= r;
+    }
+    return a;
+}
+// vec3.h:95-97, Sarrus with the reference's association
+__device__ __forceinline__ double det3(V3 a, V3 b, V3 c) {
+    return (a.x * b.y * c.z + b.x * c.y * a.z + c.x * a.y * b.z - a.x * c.y * b.z - b.x * a.y * c.z -
+            c.x * b.y * a.z);
+}
+__device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+
+// =====================================================================================================
+// kernel parameters
+// =====================================================================================================
+struct GridParams {
+    int32_t W, H, rows, row_offset, stripe_rows, stripe_rank, stripe_nranks;
+    int32_t spp, sample_offset, max_depth;
+    double inv_spp_total;
+    uint64_t seed;
+    double cam[3], half_width, focus_plane, lens_radius;
+};
+
+static constexpr int kTileW = 32, kTileH = 8, kThreads = 256;
+static constexpr int kMaxObjs = 96;  // top-level objects staged in LDS (12 KiB)
+
+// local row -> global row (cgrt.h: block-cyclic stripes)
+__device__ __forceinline__ int global_row(const GridParams &g, int j) {
+    if (g.stripe_nranks > 1) {
+        int S = g.stripe_rows;
+        return ((j / S) * g.stripe_nranks + g.stripe_rank) * S + (j % S);
+    }
+    return g.row_offset + j;
+}
+
+// =====================================================================================================
+// tree traversal: KDTree::intersect_subtree / KDTree::intersect (objects.h:269-332)
+// =====================================================================================================
+// The reference visits BOTH children of every inner node whose box the ray touches, scans every leaf it
+// reaches, and returns (a) the nearest triangle hit, ties resolved "first triangle inside a leaf, LAST leaf
+// across leaves" (strict < at objects.h:281 and 297) and (b) the total number of times a leaf's running minimum
+// improved, whose parity picks the normal's sign (objects.h:321-327).  Node numbering is preorder, so the
+// recursion is a linear scan with skip links; no stack is needed.
+//
+// Box test.  KDNode::intersect (objects.h:166-200) intersects the ray with each face plane of the box and
+// accepts when the crossing point lies within the face rectangle grown by 1e-4.  Whenever that accepts, the
+// ray touches the box grown by 1e-4 on all sides at some t > 0, so a slab test on the grown box accepts too.
+// Conversely a triangle of the node can only be hit at a point inside the un-grown box, where the reference's
+// exit-face test accepts with 1e-4 of margin.  So the slab test visits a superset of the reference's nodes
+// and the extra nodes cannot contain a hit: (len, triangle, counter) are identical.  The box is pre-grown by
+// kBoxPad on the host; 1/d is computed once per ray.
+//
+// Triangle test.  Triangle::intersect (objects.h:96-111) divides four determinants and compares the
+// quotients with 0 and 1.  For finite non-zero det1 the sign and "<= 1" tests on correctly rounded quotients
+// are equivalent to the sign / magnitude tests below (DESIGN.md "triangle test"), so only an accepted hit pays
+// for a division (len = det2/det1, the same correctly rounded quotient).
+struct TreeHit {
+    double len;
+    int tri;      // absolute index into tris[]
+    int counter;  // improvements (Q5)
+};
+
+template <bool STATS>
+__device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                  int nnodes, V3 o, V3 d, V3 inv, uint32_t &n_node,
+                                                  uint32_t &n_tri) {
+    TreeHit r;
+    r.len = kInf;
+    r.tri = -1;
+    r.counter = 0;
+    int i = 0;
+    while (i < nnodes) {
+        const NodeRec *nd = nodes + i;
+        if (STATS) n_node++;
+        double t1, t2, tn, tf;
+        t1 = (nd->lo[0] - o.x) * inv.x;
+        t2 = (nd->hi[0] - o.x) * inv.x;
+        tn = fmin(t1, t2);
+        tf = fmax(t1, t2);
+        t1 = (nd->lo[1] - o.y) * inv.y;
+        t2 = (nd->hi[1] - o.y) * inv.y;
+        tn = fmax(tn, fmin(t1, t2));
+        tf = fmin(tf, fmax(t1, t2));
+        t1 = (nd->lo[2] - o.z) * inv.z;
+        t2 = (nd->hi[2] - o.z) * inv.z;
+        tn = fmax(tn, fmin(t1, t2));
+        tf = fmin(tf, fmax(t1, t2));
+        const bool touch = (tf > 0.0) && (tn <= tf);
+        const int cnt = nd->tri_count;
+        if (!touch) {
+            i = nd->skip;
+            continue;
+        }
+        i = i + 1;  // inner: left child is next in preorder; leaf: its skip is i+1 too
+        if (cnt < 0) continue;
+        // leaf scan, objects.h:273-289
+        double leaf_len = kInf;
+        int leaf_tri = -1, leaf_cnt = 0;
+        const TriRec *tp = tris + nd->tri_begin;
+        for (int k = 0; k < cnt; k++) {
+            if (STATS) n_tri++;
+            const V3 pa = ld3(tp[k].pa), e1 = ld3(tp[k].e1), e2 = ld3(tp[k].e2);
+            const V3 s = pa - o;
+            const double det1 = det3(d, e1, e2);
+            const double det2 = det3(s, e1, e2);
+            const double det3_ = det3(d, s, e2);
+            const double det4 = det3(d, e1, s);
+            const double sg = det1 > 0.0 ? 1.0 : -1.0;
+            const double a1 = det1 * sg;
+            const bool ok = (det1 != 0.0) && (det2 * sg > 0.0) && (det3_ * sg >= 0.0) && (det4 * sg >= 0.0) &&
+                            ((det3_ + det4) * sg <= a1);
+            if (ok) {
+                const double len = det2 / det1;
+                if (len < leaf_len) {
+                    leaf_len = len;
+                    leaf_tri = nd->tri_begin + k;
+                    leaf_cnt++;
+                }
+            }
+        }
+        if (leaf_cnt > 0) {
+            // objects.h:295-313: the left result survives only if strictly nearer => later leaf wins ties
+            if (r.counter == 0 || !(r.len < leaf_len)) {
+                r.len = leaf_len;
+                r.tri = leaf_tri;
+            }
+            r.counter += leaf_cnt;
+        }
+    }
+    return r;
+}
+
+// normal of the winning triangle, oriented by the improvement-counter parity (objects.h:107,321-327)
+__device__ __forceinline__ V3 tree_normal(const TriRec *__restrict__ tris, const TreeHit &h, V3 d) {
+    const V3 e1 = ld3(tris[h.tri].e1), e2 = ld3(tris[h.tri].e2);
+    V3 n = normalized(cross(e1, e2));
+    const bool facing = dot(n, d) < 0;
+    if ((h.counter & 1) == 0) {
+        if (!facing) n = -n;  // origin outside: normal against the ray
+    } else {
+        if (facing) n = -n;  // origin inside: normal along the ray
+    }
+    return n;
+}
+
+// =====================================================================================================
+// Texture::color, texture.h:39-72 (nearest texel, three axis-aligned orientations, d.x tested first)
+// =====================================================================================================
+__device__ __forceinline__ bool texture_color(const TexRec &t, const uint8_t *__restrict__ texels, V3 point, V3 &out) {
+    V3 d = point - ld3(t.p);
+    const V3 n = ld3(t.n);
+    d = d - n * dot(d, n);
+    const double te = 1e-2;  // texture.h:12
+    const int rows = t.rows, cols = t.cols;
+    int r, c;
+    if (d.x < te && d.x > -te) {
+        if (!(0 < d.y && d.y < t.lenx && 0 < d.z && d.z < t.leny)) return false;
+        r = (int)floor(d.y / t.lenx * rows);
+        c = (int)floor(d.z / t.leny * cols);
+    } else if (d.y < te && d.y > -te) {
+        if (!(0 < d.x && d.x < t.lenx && 0 < d.z && d.z < t.leny)) return false;
+        c = (int)floor(d.x / t.lenx * cols);
+        r = (int)floor(d.z / t.leny * rows);
+    } else if (d.z < te && d.z > -te) {
+        if (!(0 < d.x && d.x < t.lenx && 0 < d.y && d.y < t.leny)) return false;
+        c = (int)floor(d.x / t.lenx * cols);
+        r = rows - 1 - (int)floor(d.y / t.leny * rows);
+    } else {
+        return false;
+    }
+    // the reference indexes unchecked; an index equal to rows/cols can only arise from rounding at the far edge
+    r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+    c = c < 0 ? 0 : (c >= cols ? cols - 1 : c);
+    const uint8_t *px = texels + t.texel_begin + 3 * ((int64_t)r * cols + c);
+    out = mk((double)px[0] / 256.0, (double)px[1] / 256.0, (double)px[2] / 256.0);  // main.cpp:307-311
+    return true;
+}
+
+// =====================================================================================================
+// nearest hit over objs (main.cpp:55-63) -- all lanes walk the LDS-resident list in lockstep
+// =====================================================================================================
+struct SceneHit {
+    double t;
+    int id;  // -1: miss
+    V3 n;    // geometric normal as the object's intersect() returns it (before main.cpp:73-76)
+};
+
+template <bool TREES, bool STATS>
+__device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
+                                                    V3 o, V3 d, uint32_t &n_node, uint32_t &n_tri) {
+    SceneHit best;
+    best.t = kInf;  // `nearest = INF`, main.cpp:54
+    best.id = -1;
+    best.n = mk(0, 0, 0);
+    int nsrc = 0;  // 0: sphere (normal derived after the loop), 1: stored in best.n
+    V3 inv = mk(0, 0, 0);
+    if (TREES) inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    for (int i = 0; i < n_objs; i++) {
+        const ObjRec &ob = objs[i];
+        const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
+        if (kind == KIND_SPHERE) {
+            // Sphere::intersect, objects.h:45-68
+            const V3 l = ld3(ob.a) - o;
+            const double tca = dot(l, d);
+            const double l2 = dot(l, l);
+            const double r2 = ob.s0;
+            if (!(tca < 0 && l2 > r2)) {
+                const double d2 = l2 - tca * tca;
+                if (!(d2 > r2)) {
+                    const double thc = sqrt(r2 - d2);
+                    const double t0 = tca - thc, t1 = tca + thc;
+                    const double len = (t0 < 0) ? t1 : t0;
+                    if (len < best.t) {
+                        best.t = len;
+                        best.id = i;
+                        nsrc = 0;
+                    }
+                }
+            }
+        } else if (kind == KIND_PLANE) {
+            // Plane::intersect, objects.h:505-524
+            const V3 pn = ld3(ob.b);
+            const V3 dd = ld3(ob.a) - o;
+            double len = dot(dd, pn) / dot(d, pn);
+            if (len > 0) {
+                V3 nrm = pn;
+                if (TREES) {
+                    const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
+                    if (tr >= 0) {
+                        const TreeRec T = sc.trees[tr];
+                        TreeHit h = tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d,
+                                                          inv, n_node, n_tri);
+                        if (h.counter > 0 && h.len < len && h.len > 0) {
+                            len = h.len;
+                            nrm = tree_normal(sc.tris + T.tri_begin, h, d);
+                        }
+                    }
+                }
+                if (len < best.t) {
+                    best.t = len;
+                    best.id = i;
+                    best.n = nrm;
+                    nsrc = 1;
+                }
+            }
+        } else if (TREES && kind == KIND_MESH) {
+            // TriangleMesh::intersect, objects.h:405-455
+            const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
+            const TreeRec T = sc.trees[tr];
+            TreeHit h = tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d, inv,
+                                              n_node, n_tri);
+            if (h.counter > 0 && h.len < best.t) {
+                V3 nrm = tree_normal(sc.tris + T.tri_begin, h, d);
+                if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436
+                best.t = h.len;
+                best.id = i;
+                best.n = nrm;
+                nsrc = 1;
+            }
+        }
+    }
+    if (best.id >= 0 && nsrc == 0) {
+        const V3 p = o + d * best.t;  // objects.h:65-66
+        best.n = normalized(p - ld3(objs[best.id].a));
+    }
+    return best;
+}
+
+// =====================================================================================================
+// the eye pass
+// =====================================================================================================
+struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
+    V3 o, d, adj;
+    int32_t depth_left;
+    uint32_t path;
+};
+
+template <bool TREES, bool DOF, bool STATS>
+__global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+                                                             uint32_t *__restrict__ nhit_out,
+                                                             unsigned long long *__restrict__ counters) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw);
+    float *ltile = reinterpret_cast<float *>(lds_raw + (size_t)kMaxObjs * sizeof(ObjRec));  // [kTileH][kTileW*3]
+
+    // stage the primitive list in LDS (128 B records, copied as 16-byte pieces)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.objs);
+        uint4 *dst = reinterpret_cast<uint4 *>(lobjs);
+        const int n16 = sc.n_objs * (int)(sizeof(ObjRec) / 16);
+        for (int k = threadIdx.x; k < n16; k += kThreads) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    const int tiles_x = (g.W + kTileW - 1) / kTileW;
+    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = (wave & 1) * 16 + (lane & 15);
+    const int ly = (wave >> 1) * 4 + (lane >> 4);
+    const int w = tile_x * kTileW + lx;
+    const int j = tile_y * kTileH + ly;  // local row
+    const int h = global_row(g, j);
+    const bool live = (w < g.W) && (j < g.rows) && (h < g.H);
+
+    const V3 camorg = mk(g.cam[0], g.cam[1], g.cam[2]);
+    // main.cpp:188-189,198,203
+    const double px = (2.0 * ((double)w / g.W) - 1) * g.half_width;
+    const double py = (2.0 * ((double)h / g.H) - 1) * g.half_width * g.H / g.W;
+    const V3 pdir = normalized(mk(px, py, 0) - camorg);
+    const V3 pof = pdir * ((g.focus_plane - camorg.z) / pdir.z) + camorg;
+    const uint64_t pixel_id = (uint64_t)h * (uint64_t)g.W + (uint64_t)w;
+
+    double acc_r = 0, acc_g = 0, acc_b = 0;
+    uint32_t my_hits = 0, my_rays = 0, my_nodes = 0, my_tris = 0, wave_iters = 0;
+
+    Pending stack[kMaxDepth - 1];
+    int sp = 0;
+    int s = 0;  // next sample to start
+    bool have = false;
+    V3 o = camorg, d = pdir, adj = mk(1, 1, 1);
+    int depth_left = 0;
+    uint32_t path = 1;
+
+    while (true) {
+        if (!have) {
+            if (live && s < g.spp) {
+                // start the next sample of this lane's pixel (main.cpp:204-209)
+                if (DOF) {
+                    Stream rs{stream_key(g.seed, pixel_id, (uint64_t)(g.sample_offset + s), 0), 0};
+                    double sx, sy;
+                    while (true) {  // uniform_sampling_circle, sampling.h:35-43
+                        sx = rs.u01() * 2.0 - 1;
+                        sy = rs.u01() * 2.0 - 1;
+                        if (sx * sx + sy * sy < 1) break;
+                    }
+                    o = camorg + mk(sx, sy, 0) * g.lens_radius;
+                    d = normalized(pof - o);
+                } else {
+                    o = camorg;
+                    d = pdir;
+                }
+                adj = mk(1, 1, 1);
+                depth_left = g.max_depth;
+                path = 1;
+                s++;
+                have = true;
+            }
+        }
+        if (__ballot(have) == 0ull) break;  // every lane of the wave has drained its pixel
+        wave_iters++;
+        if (have) {
+            my_rays++;
+            const SceneHit hit = intersect_scene<TREES, STATS>(lobjs, sc.n_objs, sc, o, d, my_nodes, my_tris);
+            have = false;
+            if (hit.id >= 0) {
+                const ObjRec &ob = lobjs[hit.id];
+                const V3 P = o + d * hit.t;  // main.cpp:68
+                V3 n = hit.n;
+                const V3 n_old = n;
+                bool into = true;
+                if (dot(n, d) > 0) {  // main.cpp:73-76
+                    n = -n;
+                    into = false;
+                }
+                V3 f = ld3(ob.col);  // getSurfaceColor
+                if (ob.kind == KIND_PLANE && ob.tex >= 0) {
+                    V3 c;
+                    if (texture_color(sc.texs[ob.tex], sc.texels, P, c)) f = c;  // objects.h:533-539
+                }
+                const double refl = ob.refl, transp = ob.transp;
+                if (refl < kEps && transp < kEps) {
+                    // diffuse: the reference stores Hitpoint{f*adj,...} (main.cpp:85-100); we accumulate it
+                    const V3 hf = mulv(f, adj);
+                    acc_r += hf.x;
+                    acc_g += hf.y;
+                    acc_b += hf.z;
+                    my_hits++;
+                } else if (depth_left > 1) {
+                    if (transp < kEps) {
+                        // mirror, main.cpp:129-134
+                        const V3 nd = d - n * 2.0 * dot(n, d);
+                        adj = mulv(f, adj) * refl;
+                        o = P + n * kEps;
+                        d = nd;
+                        depth_left--;
+                        path = path * 2;
+                        have = true;
+                    } else {
+                        // glass, main.cpp:135-157
+                        const double nc = 1.0, nt = 1.33;
+                        const double nnt = into ? nc / nt : nt / nc;
+                        const double ddn = dot(d, n);
+                        const V3 refl_dir = d - n_old * 2.0 * dot(n_old, d);
+                        const double cos2t = 1 - nnt * nnt * (1 - ddn * ddn);
+                        if (cos2t < 0) {
+                            // total internal reflection keeps adj (main.cpp:144)
+                            o = P + n * kEps;
+                            d = refl_dir;
+                        } else {
+                            const V3 refr_dir =
+                                normalized(d * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
+                            const double a = nt - nc, b = nt + nc, R0 = a * a / (b * b);
+                            const double c = 1 - (into ? -ddn : dot(refr_dir, n_old));
+                            const double Re = R0 + (1 - R0) * c * c * c * c * c;
+                            const V3 fa = mulv(f, adj);
+                            Pending &pe = stack[sp++];
+                            pe.o = P - n * kEps;
+                            pe.d = refr_dir;
+                            pe.adj = fa * (1 - Re);
+                            pe.depth_left = depth_left - 1;
+                            pe.path = path * 2 + 1;
+                            o = P + n * kEps;
+                            d = refl_dir;
+                            adj = fa * Re;
+                        }
+                        depth_left--;
+                        path = path * 2;
+                        have = true;
+                    }
+                }
+            }
+            if (!have && sp > 0) {
+                const Pending &pe = stack[--sp];
+                o = pe.o;
+                d = pe.d;
+                adj = pe.adj;
+                depth_left = pe.depth_left;
+                path = pe.path;
+                have = true;
+            }
+        }
+    }
+
+    // ---- coalesced store through LDS: 32 px x 3 floats = 384 contiguous bytes per tile row ----
+    ltile[ly * (kTileW * 3) + lx * 3 + 0] = (float)(acc_r * g.inv_spp_total);
+    ltile[ly * (kTileW * 3) + lx * 3 + 1] = (float)(acc_g * g.inv_spp_total);
+    ltile[ly * (kTileW * 3) + lx * 3 + 2] = (float)(acc_b * g.inv_spp_total);
+    __syncthreads();
+    for (int k = threadIdx.x; k < kTileH * kTileW * 3; k += kThreads) {
+        const int row = k / (kTileW * 3), col = k % (kTileW * 3);
+        const int jj = tile_y * kTileH + row;
+        const int ww = tile_x * kTileW + col / 3;
+        if (jj < g.rows && ww < g.W) rgb[((size_t)jj * g.W + tile_x * kTileW) * 3 + col] = ltile[k];
+    }
+    if (nhit_out && (w < g.W) && (j < g.rows)) nhit_out[(size_t)j * g.W + w] = my_hits;
+
+    if (counters) {
+        // wave reduction, then one atomic per wave and counter
+        unsigned long long r = my_rays, hh = my_hits, nn = my_nodes, tt = my_tris;
+        for (int off = 32; off > 0; off >>= 1) {
+            r += __shfl_xor(r, off);
+            hh += __shfl_xor(hh, off);
+            if (STATS) {
+                nn += __shfl_xor(nn, off);
+                tt += __shfl_xor(tt, off);
+            }
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[CGRT_CNT_RAYS], r);
+            atomicAdd(&counters[CGRT_CNT_HITPOINTS], hh);
+            atomicAdd(&counters[CGRT_CNT_WAVE_ITERS], (unsigned long long)wave_iters);
+            if (STATS) {
+                atomicAdd(&counters[CGRT_CNT_NODE_TESTS], nn);
+                atomicAdd(&counters[CGRT_CNT_TRI_TESTS], tt);
+            }
+        }
+    }
+}
+
+// function-level probe: one object, n rays (cgrt_intersect_rays)
+__global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__restrict__ org,
+                                      const double *__restrict__ dir, int n, int32_t *__restrict__ hit,
+                                      double *__restrict__ len, double *__restrict__ nrm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t a = 0, b = 0;
+    const V3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
+    DeviceScene one = sc;
+    SceneHit h = intersect_scene<true, false>(sc.objs + obj, 1, one, o, d, a, b);
+    hit[i] = h.id >= 0 ? 1 : 0;
+    len[i] = h.t;
+    nrm[3 * i] = h.n.x;
+    nrm[3 * i + 1] = h.n.y;
+    nrm[3 * i + 2] = h.n.z;
+}
+
+// =====================================================================================================
+// host side: scene handle, upload, C ABI
+// =====================================================================================================
+struct cgrt_scene {
+    HostScene host;
+    bool committed = false;
+    int device = -1;
+    DeviceScene dev{};
+    std::vector<void *> allocs;
+    int64_t device_bytes = 0;
+    std::vector<int> tree_of;  // flat tree list (object order)
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(CGRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+static int upload(cgrt_scene *s, const std::vector<T> &v, const T **out) {
+    *out = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);  // keep pointers non-null
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    s->device_bytes += (int64_t)bytes;
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T *>(p);
+    return CGRT_OK;
+}
+
+extern "C" {
+
+int cgrt_version(void) { return CGRT_VERSION; }
+const char *cgrt_last_error(void) { return g_err.c_str(); }
+
+int cgrt_scene_create(cgrt_scene **out) {
+    if (!out) return fail(CGRT_ERR_INVALID, "cgrt_scene_create: null out");
+    *out = new (std::nothrow) cgrt_scene();
+    return *out ? CGRT_OK : fail(CGRT_ERR_INVALID, "out of memory");
+}
+
+void cgrt_scene_destroy(cgrt_scene *s) {
+    if (!s) return;
+    if (!s->allocs.empty()) {
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            (void)hipSetDevice(s->device);
+            for (void *p : s->allocs) (void)hipFree(p);
+            (void)hipSetDevice(cur);
+        }
+    }
+    delete s;
+}
+
+#define NEED_OPEN(s)                                                          \
+    if (!(s)) return fail(CGRT_ERR_INVALID, "null scene");                    \
+    if ((s)->committed) return fail(CGRT_ERR_INVALID, "scene already committed")
+
+static int added(cgrt_scene *s, int r) {
+    if (r == -2) return fail(CGRT_ERR_IO, s->host.error);
+    if (r < 0) return fail(CGRT_ERR_INVALID, s->host.error);
+    if ((int)s->host.objs.size() > kMaxObjs) return fail(CGRT_ERR_LIMIT, "more than 96 top-level objects");
+    return r;
+}
+
+int cgrt_scene_add_sphere(cgrt_scene *s, const double c[3], double r, const double sc[3], double refl, double transp) {
+    NEED_OPEN(s);
+    if (!c || !sc) return fail(CGRT_ERR_INVALID, "null argument");
+    return added(s, s->host.add_sphere(c, r, sc, refl, transp));
+}
+int cgrt_scene_add_texture(cgrt_scene *s, const uint8_t *rgb, int rows, int cols, const double n[3], const double p[3],
+                           double lx, double ly, int isbump) {
+    NEED_OPEN(s);
+    if (!n || !p) return fail(CGRT_ERR_INVALID, "null argument");
+    int r = s->host.add_texture(rgb, rows, cols, n, p, lx, ly, isbump);
+    return r < 0 ? fail(CGRT_ERR_INVALID, s->host.error) : r;
+}
+int cgrt_scene_add_plane(cgrt_scene *s, const double p[3], const double n[3], const double sc[3], double refl,
+                         double transp, int tex_id) {
+    NEED_OPEN(s);
+    if (!p || !n || !sc) return fail(CGRT_ERR_INVALID, "null argument");
+    return added(s, s->host.add_plane(p, n, sc, refl, transp, tex_id));
+}
+int cgrt_scene_add_mesh_file(cgrt_scene *s, const char *filename, double a, const double b[3], const double sc[3],
+                             double refl, double transp, int typeofdata) {
+    NEED_OPEN(s);
+    if (!filename || !b || !sc) return fail(CGRT_ERR_INVALID, "null argument");
+    return added(s, s->host.add_mesh_file(filename, a, b, sc, refl, transp, typeofdata));
+}
+int cgrt_scene_add_mesh_triangles(cgrt_scene *s, const double *tri9, int ntri, const double sc[3], double refl,
+                                  double transp, int typeofdata) {
+    NEED_OPEN(s);
+    if (!sc) return fail(CGRT_ERR_INVALID, "null argument");
+    return added(s, s->host.add_mesh_triangles(tri9, ntri, sc, refl, transp, typeofdata));
+}
+int cgrt_scene_add_bezier(cgrt_scene *s, const double *cp3, int ncp, const double pos[3], const double sc[3],
+                          double refl, double transp) {
+    NEED_OPEN(s);
+    if (!pos || !sc) return fail(CGRT_ERR_INVALID, "null argument");
+    return added(s, s->host.add_bezier(cp3, ncp, pos, sc, refl, transp));
+}
+
+int cgrt_scene_commit(cgrt_scene *s, int device) {
+    NEED_OPEN(s);
+    if (!s->host.beziers.empty()) return fail(CGRT_ERR_UNSUPPORTED, "Bezier objects are not yet traced on the device");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CGRT_ERR_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    s->device = device;
+    HostScene &H = s->host;
+    // flatten trees
+    std::vector<NodeRec> nodes;
+    std::vector<TriRec> tris;
+    std::vector<TreeRec> trees;
+    for (auto &t : H.trees) {
+        TreeRec tr;
+        tr.node_begin = (int64_t)nodes.size();
+        tr.tri_begin = (int64_t)tris.size();
+        tr.nnodes = (int32_t)t.nodes.size();
+        tr.ntris = (int32_t)t.tris.size();
+        nodes.insert(nodes.end(), t.nodes.begin(), t.nodes.end());
+        tris.insert(tris.end(), t.tris.begin(), t.tris.end());
+        trees.push_back(tr);
+    }
+    std::vector<TexRec> texs;
+    std::vector<uint8_t> texels;
+    for (auto &t : H.textures) {
+        TexRec tr;
+        std::memset(&tr, 0, sizeof(tr));
+        tr.texel_begin = (int64_t)texels.size();
+        tr.rows = t.rows;
+        tr.cols = t.cols;
+        for (int k = 0; k < 3; k++) {
+            tr.n[k] = t.n[k];
+            tr.p[k] = t.p[k];
+        }
+        tr.lenx = t.lenx;
+        tr.leny = t.leny;
+        tr.isbump = t.isbump ? 1 : 0;
+        texels.insert(texels.end(), t.rgb.begin(), t.rgb.end());
+        texs.push_back(tr);
+    }
+    DeviceScene d{};
+    int rc;
+    if ((rc = upload(s, H.objs, &d.objs))) return rc;
+    if ((rc = upload(s, nodes, &d.nodes))) return rc;
+    if ((rc = upload(s, tris, &d.tris))) return rc;
+    if ((rc = upload(s, trees, &d.trees))) return rc;
+    if ((rc = upload(s, texs, &d.texs))) return rc;
+    if ((rc = upload(s, texels, &d.texels))) return rc;
+    if ((rc = upload(s, H.beziers, &d.beziers))) return rc;
+    d.n_objs = (int32_t)H.objs.size();
+    d.n_trees = (int32_t)trees.size();
+    d.n_texs = (int32_t)texs.size();
+    d.n_beziers = (int32_t)H.beziers.size();
+    d.has_mesh = trees.empty() ? 0 : 1;
+    d.has_bezier = H.beziers.empty() ? 0 : 1;
+    d.all_spheres = 1;
+    for (auto &o : H.objs)
+        if (o.kind != KIND_SPHERE) d.all_spheres = 0;
+    s->dev = d;
+    s->committed = true;
+    return CGRT_OK;
+}
+
+int cgrt_scene_get_stats(const cgrt_scene *s, cgrt_scene_stats *out) {
+    if (!s || !out) return fail(CGRT_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    const HostScene &H = s->host;
+    out->n_objects = (int32_t)H.objs.size();
+    int64_t bytes = 0;
+    for (auto &o : H.objs) {
+        if (o.kind == KIND_SPHERE) { out->n_spheres++; bytes += 88; }
+        if (o.kind == KIND_PLANE) { out->n_planes++; bytes += 100; }
+        if (o.kind == KIND_MESH) out->n_meshes++;
+        if (o.kind == KIND_BEZIER) { out->n_beziers++; bytes += 24 * 6 + 100; }
+    }
+    out->n_textures = (int32_t)H.textures.size();
+    out->n_trees = (int32_t)H.trees.size();
+    for (auto &t : H.trees) {
+        out->n_triangles += (int64_t)t.tris.size();
+        out->n_nodes += (int64_t)t.nodes.size();
+    }
+    bytes += 56 * out->n_nodes + 72 * out->n_triangles;
+    for (auto &t : H.textures) bytes += 3 * (int64_t)t.rows * t.cols;
+    out->scene_bytes_fp64 = bytes;
+    out->device_bytes = s->device_bytes;
+    out->committed = s->committed ? 1 : 0;
+    return CGRT_OK;
+}
+
+int cgrt_scene_tree_sizes(const cgrt_scene *s, int t, int32_t *nnodes, int32_t *nleaftris, int32_t *ntris) {
+    if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
+    const HostTree &T = s->host.trees[t];
+    if (nnodes) *nnodes = (int32_t)T.nodes.size();
+    if (nleaftris) *nleaftris = (int32_t)T.leaf_ids.size();
+    if (ntris) *ntris = (int32_t)(T.tri9.size() / 9);
+    return CGRT_OK;
+}
+int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int32_t *leaf_ids, double *bbox,
+                         double *tri9) {
+    if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
+    const HostTree &T = s->host.trees[t];
+    if (node_lr_size) std::memcpy(node_lr_size, T.node_lr_size.data(), T.node_lr_size.size() * sizeof(int32_t));
+    if (leaf_ids) std::memcpy(leaf_ids, T.leaf_ids.data(), T.leaf_ids.size() * sizeof(int32_t));
+    if (bbox) std::memcpy(bbox, T.bbox.data(), T.bbox.size() * sizeof(double));
+    if (tri9) std::memcpy(tri9, T.tri9.data(), T.tri9.size() * sizeof(double));
+    return CGRT_OK;
+}
+
+static int check_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *g) {
+    if (!s || !cam || !g) return fail(CGRT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(CGRT_ERR_INVALID, "scene not committed");
+    if (g->width <= 0 || g->height <= 0 || g->rows <= 0) return fail(CGRT_ERR_INVALID, "empty grid");
+    if (g->spp <= 0 || g->spp_total <= 0 || g->sample_offset < 0) return fail(CGRT_ERR_INVALID, "bad sample range");
+    if (g->max_depth < 1 || g->max_depth > kMaxDepth) return fail(CGRT_ERR_INVALID, "max_depth must be 1..5");
+    if (g->stripe_nranks > 1) {
+        if (g->stripe_rows <= 0 || g->stripe_rows % kTileH != 0)
+            return fail(CGRT_ERR_INVALID, "stripe_rows must be a positive multiple of 8");
+        if (g->stripe_rank < 0 || g->stripe_rank >= g->stripe_nranks) return fail(CGRT_ERR_INVALID, "bad stripe_rank");
+    } else if (g->row_offset < 0) {
+        return fail(CGRT_ERR_INVALID, "bad row_offset");
+    }
+    if (!(cam->lens_radius >= 0)) return fail(CGRT_ERR_INVALID, "lens_radius must be >= 0");
+    return CGRT_OK;
+}
+
+int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb, uint32_t *nhit,
+                    uint64_t *counters, void *stream) {
+    int rc = check_grid(s, cam, grid);
+    if (rc) return rc;
+    if (!rgb) return fail(CGRT_ERR_INVALID, "null rgb");
+    GridParams g;
+    g.W = grid->width;
+    g.H = grid->height;
+    g.rows = grid->rows;
+    g.row_offset = grid->row_offset;
+    g.stripe_rows = grid->stripe_rows;
+    g.stripe_rank = grid->stripe_rank;
+    g.stripe_nranks = grid->stripe_nranks;
+    g.spp = grid->spp;
+    g.sample_offset = grid->sample_offset;
+    g.max_depth = grid->max_depth;
+    g.inv_spp_total = 1.0 / (double)grid->spp_total;
+    g.seed = grid->seed;
+    for (int k = 0; k < 3; k++) g.cam[k] = cam->cam[k];
+    g.half_width = cam->half_width;
+    g.focus_plane = cam->focus_plane;
+    g.lens_radius = cam->lens_radius;
+
+    const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
+    const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
+    const size_t lds = (size_t)kMaxObjs * sizeof(ObjRec) + (size_t)kTileH * kTileW * 3 * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto *cnt = reinterpret_cast<unsigned long long *>(counters);
+    const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0;
+    const bool stats = (grid->flags & 1) != 0;
+#define LAUNCH(T, D, S) \
+    hipLaunchKernelGGL((trace_grid_kernel<T, D, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
+    if (trees) {
+        if (dof) { if (stats) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+        else     { if (stats) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+    } else {
+        if (dof) LAUNCH(false, true, false); else LAUNCH(false, false, false);
+    }
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return CGRT_OK;
+}
+
+int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,
+                         uint32_t *nhit, uint64_t *counters) {
+    int rc = check_grid(s, cam, grid);
+    if (rc) return rc;
+    if (!rgb) return fail(CGRT_ERR_INVALID, "null rgb");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)grid->rows * grid->width;
+    float *d_rgb = nullptr;
+    uint32_t *d_nhit = nullptr;
+    uint64_t *d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rgb, npx * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_nhit, npx * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&d_cnt, CGRT_NCOUNTERS * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(d_rgb, 0, npx * 3 * sizeof(float)));
+    HIP_TRY(hipMemset(d_nhit, 0, npx * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(d_cnt, 0, CGRT_NCOUNTERS * sizeof(uint64_t)));
+    rc = cgrt_trace_grid(s, cam, grid, d_rgb, d_nhit, d_cnt, nullptr);
+    if (rc == CGRT_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = fail(CGRT_ERR_DEVICE, std::string("kernel: ") + hipGetErrorString(e));
+    }
+    if (rc == CGRT_OK) {
+        HIP_TRY(hipMemcpy(rgb, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (nhit) HIP_TRY(hipMemcpy(nhit, d_nhit, npx * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (counters) HIP_TRY(hipMemcpy(counters, d_cnt, CGRT_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_nhit);
+    (void)hipFree(d_cnt);
+    return rc;
+}
+
+int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const double *dir3, const uint64_t *keys,
+                        int n, int32_t *hit, double *len, double *normal3) {
+    (void)keys;
+    if (!s || !s->committed) return fail(CGRT_ERR_INVALID, "scene not committed");
+    if (obj < 0 || obj >= s->dev.n_objs || n < 0 || !org3 || !dir3 || !hit || !len || !normal3)
+        return fail(CGRT_ERR_INVALID, "bad argument");
+    if (n == 0) return CGRT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    double *d_o = nullptr, *d_d = nullptr, *d_len = nullptr, *d_n = nullptr;
+    int32_t *d_hit = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_o, (size_t)n * 24));
+    HIP_TRY(hipMalloc((void **)&d_d, (size_t)n * 24));
+    HIP_TRY(hipMalloc((void **)&d_len, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void **)&d_n, (size_t)n * 24));
+    HIP_TRY(hipMalloc((void **)&d_hit, (size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_o, org3, (size_t)n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, dir3, (size_t)n * 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(intersect_rays_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, obj, d_o, d_d, n, d_hit,
+                       d_len, d_n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(normal3, d_n, (size_t)n * 24, hipMemcpyDeviceToHost));
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_len); (void)hipFree(d_n); (void)hipFree(d_hit);
+    return CGRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// POD layouts shared by the host-side scene builder (cgrt_build.cpp) and the gfx950 kernels (cgrt_hip.hip).
+// Everything the kernels read lives in these structs; the flattened scene is uploaded once at commit.
+#ifndef CGRT_TYPES_H
+#define CGRT_TYPES_H
+#include <stdint.h>
+
+namespace cgrt {
+
+// Reference constants (main.cpp:24-25, objects.h:15,143-144).
+static constexpr double kEps = 1e-4;       // main.cpp:24  ray-origin offset and material thresholds
+static constexpr double kInf = 1e10;       // main.cpp:25 / objects.h:15
+static constexpr int kMinKd = 10;          // objects.h:143  leaf iff triangle count < 10
+static constexpr double kBoxPad = 1.001e-4;// objects.h:144 pads boxes by 1e-4; see DESIGN.md "box test" for the slack
+static constexpr int kMaxDepth = 5;        // main.cpp:35
+
+enum ObjKind : int32_t { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_MESH = 2, KIND_BEZIER = 3 };
+
+// One entry per top-level object, in `objs` order.  Staged in LDS by every workgroup.
+// 16 doubles = 128 B.
+struct ObjRec {
+    // sphere: a = centre, s0 = radius^2                       (objects.h:83-88)
+    // plane : a = position, b = normal                         (objects.h:541-542)
+    // mesh  : (nothing)                                         (objects.h:470-475)
+    // bezier: a = position, b.x = cp[last].z, index -> BezierRec (bezier.h:303-313)
+    double a[3];
+    double b[3];
+    double s0;
+    double col[3];        // surfaceColor
+    double refl, transp;  // reflection, transparency
+    int32_t kind;
+    int32_t tree;         // mesh: tree index; plane: bump tree index or -1
+    int32_t tex;          // plane: texture index or -1
+    int32_t aux;          // mesh: objtype (objects.h:434); bezier: index into beziers[]
+    int32_t pad0, pad1, pad2, pad3;
+};
+static_assert(sizeof(ObjRec) == 128, "ObjRec layout");
+
+// Tree node in the reference's preorder numbering (objects.h:217-226), with a skip link instead of
+// child indices: next node when the subtree is abandoned.  Box already padded by kBoxPad.  64 B.
+struct NodeRec {
+    double lo[3];
+    double hi[3];
+    int32_t skip;       // index of the first node after this subtree
+    int32_t tri_begin;  // leaves: first triangle in TriRec order
+    int32_t tri_count;  // leaves: 0..9 ; inner nodes: -1
+    int32_t pad;
+};
+static_assert(sizeof(NodeRec) == 64, "NodeRec layout");
+
+// Leaf triangle, stored in leaf order: pa and the two edge vectors the reference recomputes per test
+// (e1 = pa-pb, e2 = pa-pc, objects.h:98-99; same doubles).  72 B.
+struct TriRec {
+    double pa[3];
+    double e1[3];
+    double e2[3];
+};
+
+struct TreeRec {
+    int64_t node_begin;  // into nodes[]
+    int64_t tri_begin;   // into tris[]
+    int32_t nnodes;
+    int32_t ntris;
+};
+
+struct TexRec {
+    int64_t texel_begin;  // into texels[] (3 bytes per texel, row-major)
+    int32_t rows, cols;
+    double n[3];
+    double p[3];
+    double lenx, leny;
+    int32_t isbump;
+    int32_t pad;
+};
+
+struct BezierRec {
+    double cp[6][3];
+    int32_t ncp;
+    int32_t pad;
+    double box[6];  // xmin,xmax,ymin,ymax,zmin,zmax (bezier.h:64-69)
+};
+
+// Kernel argument block.
+struct DeviceScene {
+    const ObjRec *objs;
+    const NodeRec *nodes;
+    const TriRec *tris;
+    const TreeRec *trees;
+    const TexRec *texs;
+    const uint8_t *texels;
+    const BezierRec *beziers;
+    int32_t n_objs, n_trees, n_texs, n_beziers;
+    int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
+    int32_t has_bezier;
+    int32_t all_spheres; // fast path selector
+    int32_t pad;
+};
+
+}  // namespace cgrt
+#endif

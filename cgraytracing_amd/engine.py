@@ -1,0 +1,169 @@
+"""Host-side `render(objs)` over the C ABI: flattens a list of scene objects into a cgrt_scene handle and
+launches the eye pass (the loop nest of main.cpp:185-219) on the GPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import Camera as _CCamera
+from ._capi import Grid as _CGrid
+from ._capi import check
+from .scene import Camera
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+class Scene:
+    """Owns a cgrt_scene handle.  `objs` order is the reference's `objs` order.  commit=False keeps the scene
+    on the host only (mesh loading / tree build can then be inspected without a GPU)."""
+
+    def __init__(self, objs, device=0, commit=True):
+        L = _capi.lib()
+        h = C.c_void_p()
+        check(L.cgrt_scene_create(C.byref(h)))
+        self._h = h
+        self._L = L
+        self.device = int(device)
+        self.obj_index = []
+        tex_ids = {}
+        try:
+            for o in objs:
+                k = o.kind
+                if k == "sphere":
+                    i = L.cgrt_scene_add_sphere(h, _d3(o.center), o.radius, _d3(o.surfaceColor), o.reflection,
+                                                o.transparency)
+                elif k == "plane":
+                    tid = -1
+                    t = o.texture
+                    if t is not None:
+                        if id(t) not in tex_ids:
+                            tex_ids[id(t)] = check(L.cgrt_scene_add_texture(
+                                h, t.data.ctypes.data, t.data.shape[0], t.data.shape[1], _d3(t.normal),
+                                _d3(t.position), t.lenx, t.leny, int(t.isbump)))
+                        tid = tex_ids[id(t)]
+                    i = L.cgrt_scene_add_plane(h, _d3(o.position), _d3(o.normal), _d3(o.surfaceColor), o.reflection,
+                                               o.transparency, tid)
+                elif k == "mesh":
+                    if o.triangles is not None:
+                        i = L.cgrt_scene_add_mesh_triangles(h, o.triangles.ctypes.data, len(o.triangles),
+                                                            _d3(o.surfaceColor), o.reflection, o.transparency,
+                                                            o.typeofdata)
+                    else:
+                        i = L.cgrt_scene_add_mesh_file(h, o.filename.encode(), o.a, _d3(o.b), _d3(o.surfaceColor),
+                                                       o.reflection, o.transparency, o.typeofdata)
+                elif k == "bezier":
+                    i = L.cgrt_scene_add_bezier(h, o.cpoints.ctypes.data, len(o.cpoints), _d3(o.position),
+                                                _d3(o.surfaceColor), o.reflection, o.transparency)
+                else:
+                    raise TypeError("not a scene object: %r" % (o,))
+                self.obj_index.append(check(i))
+            if commit:
+                check(L.cgrt_scene_commit(h, self.device))
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cgrt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- introspection ----
+    def stats(self):
+        st = _capi.SceneStats()
+        check(self._L.cgrt_scene_get_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    def tree_dump(self, t=0):
+        nn, nl, nt = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self._L.cgrt_scene_tree_sizes(self._h, t, C.byref(nn), C.byref(nl), C.byref(nt)))
+        nodes = np.zeros((nn.value, 3), np.int32)
+        leaf = np.zeros((nl.value,), np.int32)
+        bbox = np.zeros((nn.value, 6), np.float64)
+        tris = np.zeros((nt.value, 9), np.float64)
+        check(self._L.cgrt_scene_tree_dump(self._h, t, nodes.ctypes.data, leaf.ctypes.data, bbox.ctypes.data,
+                                           tris.ctypes.data))
+        return nodes, leaf, bbox, tris
+
+    # ---- the hot path ----
+    def _structs(self, camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
+                 spp_total, flags):
+        camera = camera or Camera()
+        cc = _CCamera(_d3(camera.cam), camera.half_width, camera.focus_plane, camera.lens_radius)
+        s_rows, s_rank, s_n = stripe if stripe else (0, 0, 1)
+        g = _CGrid(width, height, rows, row_offset, s_rows, s_rank, s_n, spp, sample_offset,
+                   spp_total if spp_total else spp, max_depth, flags, seed)
+        return cc, g
+
+    def trace_grid(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, rows=None, row_offset=0,
+                   stripe=None, sample_offset=0, spp_total=None, out=None, nhit=None, counters=None, stream=None,
+                   stats=False):
+        """Asynchronous launch on torch's current stream (or `stream`).  Returns (rgb, nhit, counters) torch
+        tensors on the scene's device: float32 [rows,width,3], int32 [rows,width] (bit pattern uint32),
+        int64 [8] (counters are ADDED to)."""
+        import torch
+
+        rows = height - row_offset if rows is None else rows
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.zeros((rows, width, 3), dtype=torch.float32, device=dev)
+        if nhit is None:
+            nhit = torch.zeros((rows, width), dtype=torch.int32, device=dev)
+        if counters is None:
+            counters = torch.zeros((_capi.CGRT_NCOUNTERS,), dtype=torch.int64, device=dev)
+        assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (rows, width, 3)
+        cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
+                              spp_total, 1 if stats else 0)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        check(self._L.cgrt_trace_grid(self._h, C.byref(cc), C.byref(g), out.data_ptr(), nhit.data_ptr(),
+                                      counters.data_ptr(), C.c_void_p(st)))
+        return out, nhit, counters
+
+    def trace_grid_host(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, rows=None, row_offset=0,
+                        stripe=None, sample_offset=0, spp_total=None, stats=False):
+        """Synchronous form with numpy outputs (no torch needed): dict(rgb, nhit, counters)."""
+        rows = height - row_offset if rows is None else rows
+        rgb = np.zeros((rows, width, 3), np.float32)
+        nhit = np.zeros((rows, width), np.uint32)
+        cnt = np.zeros((_capi.CGRT_NCOUNTERS,), np.uint64)
+        cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
+                              spp_total, 1 if stats else 0)
+        check(self._L.cgrt_trace_grid_host(self._h, C.byref(cc), C.byref(g), rgb.ctypes.data, nhit.ctypes.data,
+                                           cnt.ctypes.data))
+        return dict(rgb=rgb, nhit=nhit, counters=cnt, nrays=int(cnt[_capi.CNT_RAYS]),
+                    nhp=int(cnt[_capi.CNT_HITPOINTS]))
+
+    def intersect_rays(self, obj, org, dirs, keys=None):
+        org = np.ascontiguousarray(org, np.float64)
+        dirs = np.ascontiguousarray(dirs, np.float64)
+        n = len(org)
+        hit = np.zeros(n, np.int32)
+        ln = np.zeros(n, np.float64)
+        nv = np.zeros((n, 3), np.float64)
+        kp = None
+        if keys is not None:
+            keys = np.ascontiguousarray(keys, np.uint64)
+            kp = keys.ctypes.data
+        check(self._L.cgrt_intersect_rays(self._h, self.obj_index[obj], org.ctypes.data, dirs.ctypes.data, kp, n,
+                                          hit.ctypes.data, ln.ctypes.data, nv.ctypes.data))
+        return hit, ln, nv
+
+
+def render(objs, width=1024, height=768, num_of_samples=1, camera=None, max_depth=5, seed=12345, device=0):
+    """Drop-in for the eye pass of render(objs) (main.cpp:169-219): returns the per-pixel accumulator
+    float32 [height, width, 3] (row 0 = bottom) as a numpy array."""
+    sc = Scene(objs, device)
+    try:
+        return sc.trace_grid_host(width, height, num_of_samples, camera, max_depth, seed)["rgb"]
+    finally:
+        sc.close()

@@ -1,0 +1,161 @@
+/*
+ * cgrt.h -- C ABI of libcgrt.so, the MI355X (gfx950) implementation of the image-grid eye-ray pass of
+ * haoyuzhao123/CGRayTracing.
+ *
+ * The reference has no plugin / FFI seam; the boundary this library replaces is the call
+ *
+ *     trace(camorg, dir, objs, Vec3(), Vec3(1,1,1), true, 0, htable, w, h);        main.cpp:209 (DoF form :207)
+ *
+ * inside the pixel/sample loop of render() (main.cpp:185-219), together with everything that call reaches:
+ * trace() main.cpp:42-100,129-157 and the intersect()/getSurfaceColor() virtuals of headers/objects.h,
+ * headers/bezier.h and headers/texture.h.  One cgrt_trace_grid() call replaces the whole loop nest for a
+ * set of image rows.  The scene-building entry points mirror the reference constructors one to one so that
+ * a host program can keep main()'s scene code shape.
+ *
+ * Conventions: plain C, no C++ or torch types.  Every function returns CGRT_OK (0) or a negative error code
+ * and never exits or throws; cgrt_last_error() gives the message for the calling thread.  Object handles are
+ * not thread-safe; distinct scenes may be used concurrently from different host threads / devices.
+ * All geometry is IEEE double, like the reference (Vec3 = 3 x double, vec3.h:11-30).
+ */
+#ifndef CGRT_H
+#define CGRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGRT_VERSION 100 /* 0.1.0 */
+
+enum {
+    CGRT_OK = 0,
+    CGRT_ERR_INVALID = -1,     /* bad argument / bad handle state                                       */
+    CGRT_ERR_IO = -2,          /* mesh file unreadable or malformed                                     */
+    CGRT_ERR_DEVICE = -3,      /* HIP runtime error (no GPU, allocation or launch failure)              */
+    CGRT_ERR_UNSUPPORTED = -4, /* feature combination not available in this build                        */
+    CGRT_ERR_LIMIT = -5        /* scene exceeds a documented limit (e.g. top-level objects per scene)    */
+};
+
+typedef struct cgrt_scene cgrt_scene; /* opaque; owns host copies and device buffers */
+
+/* Camera and lens constants of render(), main.cpp:178-181,188-206. */
+typedef struct cgrt_camera {
+    double cam[3];      /* camorg, main.cpp:181: (0,0,-10)                                              */
+    double half_width;  /* the literal 10.0 of main.cpp:188-189: image plane z=0 spans x in [-hw,hw)    */
+    double focus_plane; /* main.cpp:178: 20.0                                                            */
+    double lens_radius; /* main.cpp:179: 1.5.  0 selects the pinhole call main.cpp:209, >0 the thin-lens
+                           call main.cpp:207 with neworg = cam + disc(radius) (sampling.h:35-43)         */
+} cgrt_camera;
+
+/* Which part of the W x H x spp grid one call renders.  Compile-time constants of the reference
+ * (width,height main.cpp:28-29; MAX_DEPTH :35; num_of_samples :177) become fields here. */
+typedef struct cgrt_grid {
+    int32_t width, height;  /* global image; row 0 is the BOTTOM row (main.cpp:185,189)                  */
+    int32_t rows;           /* local rows rendered by this call = rows of the output buffers             */
+    int32_t row_offset;     /* contiguous mode (stripe_nranks <= 1): first global row                    */
+    int32_t stripe_rows;    /* block-cyclic mode: stripe height in rows (multiple of 8)                  */
+    int32_t stripe_rank;    /*   local row j is global row ((j/S)*nranks + rank)*S + j%S                 */
+    int32_t stripe_nranks;  /*   rows that fall beyond `height` are left zero                            */
+    int32_t spp;            /* samples traced by this call                                               */
+    int32_t sample_offset;  /* index of the first sample (keys the lens stream)                          */
+    int32_t spp_total;      /* normaliser: output = sum / spp_total (== spp for a single pass)           */
+    int32_t max_depth;      /* MAX_DEPTH, main.cpp:35 (1..5)                                             */
+    int32_t flags;          /* 0                                                                         */
+    uint64_t seed;          /* seed of the counter-based lens / Bezier streams                           */
+} cgrt_grid;
+
+/* indices into the uint64 counters[CGRT_NCOUNTERS] array written by cgrt_trace_grid (added to, not reset) */
+enum {
+    CGRT_CNT_RAYS = 0,      /* trace() invocations past the depth test (main.cpp:46)                     */
+    CGRT_CNT_HITPOINTS = 1, /* Hitpoints the reference would have inserted (main.cpp:98)                 */
+    CGRT_CNT_WAVE_ITERS = 2,/* wavefront loop iterations (x64 = lane slots; lane utilisation = rays/slots)*/
+    CGRT_CNT_NODE_TESTS = 3,/* tree nodes visited (lane granularity)                                     */
+    CGRT_CNT_TRI_TESTS = 4, /* triangle tests                                                            */
+    CGRT_NCOUNTERS = 8
+};
+
+typedef struct cgrt_scene_stats {
+    int32_t n_objects, n_spheres, n_planes, n_meshes, n_beziers, n_textures, n_trees, committed;
+    int64_t n_triangles;   /* leaf triangles over all trees (mesh + bump)                                */
+    int64_t n_nodes;
+    int64_t device_bytes;  /* bytes resident in HBM for this scene                                       */
+    int64_t scene_bytes_fp64; /* S_scene of SURVEY.md section 8d: 88/sphere, 100/plane, 56/node + 72/tri, 3/texel */
+} cgrt_scene_stats;
+
+int cgrt_version(void);
+const char *cgrt_last_error(void);
+
+/* ---- scene construction; each add_* returns the object's position in `objs` (>= 0) or an error (< 0).
+ *      Order matters exactly as in vector<Object*> objs (main.cpp:355-366): on equal hit distance the
+ *      earlier object wins (main.cpp:57). */
+int cgrt_scene_create(cgrt_scene **out);
+void cgrt_scene_destroy(cgrt_scene *s);
+
+/* Sphere(c, r, sc, refl, transp)                                                   objects.h:28-38 */
+int cgrt_scene_add_sphere(cgrt_scene *s, const double c[3], double r, const double sc[3], double refl, double transp);
+
+/* Texture(data, n, p, lx, ly, bump)   texture.h:19-38.  rgb = rows*cols*3 bytes as decoded (texel = byte/256,
+ * main.cpp:303-316).  Returns a texture id for cgrt_scene_add_plane. */
+int cgrt_scene_add_texture(cgrt_scene *s, const uint8_t *rgb, int rows, int cols, const double n[3],
+                           const double p[3], double lx, double ly, int isbump);
+
+/* Plane(p, n, sc, refl, transp, tx)   objects.h:480-504.  tex_id < 0: no texture.  A bump texture on a
+ * plane with |n.y-1| < 1e-5 builds the displacement mesh and its tree (objects.h:482-503). */
+int cgrt_scene_add_plane(cgrt_scene *s, const double p[3], const double n[3], const double sc[3], double refl,
+                         double transp, int tex_id);
+
+/* TriangleMesh(filename, a, b, sc, refl, transp, typeofdata)   objects.h:338-403: the three text formats,
+ * vertex -> (x, y, -z) * a + b.  A missing file yields an empty mesh like the reference; a malformed file
+ * is CGRT_ERR_IO (the reference's behaviour there is undefined). */
+int cgrt_scene_add_mesh_file(cgrt_scene *s, const char *filename, double a, const double b[3], const double sc[3],
+                             double refl, double transp, int typeofdata);
+/* Same object from ntri*9 doubles (pa, pb, pc per triangle, already transformed). */
+int cgrt_scene_add_mesh_triangles(cgrt_scene *s, const double *tri9, int ntri, const double sc[3], double refl,
+                                  double transp, int typeofdata);
+
+/* Bezier(points, pos, sc, refl, transp)   bezier.h:44-71; 1..6 control points. */
+int cgrt_scene_add_bezier(cgrt_scene *s, const double *cp3, int ncp, const double pos[3], const double sc[3],
+                          double refl, double transp);
+
+/* Builds the trees (KDTree::buildKdTree, objects.h:217-267, same leaf order), flattens the scene and uploads
+ * it to HIP device `device`.  Must be called once before tracing; the scene is immutable afterwards. */
+int cgrt_scene_commit(cgrt_scene *s, int device);
+int cgrt_scene_get_stats(const cgrt_scene *s, cgrt_scene_stats *out);
+
+/* ---- host-side prerequisites exposed for verification (tree fingerprints, loader output) ----
+ * tree index t: 0..n_trees-1 in object order (a mesh's tree, or a bump plane's tree).
+ * node_lr_size: nnodes*3 int32 (left, right, triangle count) in the reference's node numbering;
+ * leaf_ids: triangle ids of all leaves in node order; bbox: nnodes*6 (xmin,xmax,ymin,ymax,zmin,zmax).
+ * tri9: the tree's triangles in construction order.  Any pointer may be NULL. */
+int cgrt_scene_tree_sizes(const cgrt_scene *s, int t, int32_t *nnodes, int32_t *nleaftris, int32_t *ntris);
+int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int32_t *leaf_ids, double *bbox,
+                         double *tri9);
+
+/* ---- the hot path -------------------------------------------------------------------------------------
+ * Renders grid->rows rows: for every pixel and sample it runs the reference's trace(flag=true) recursion
+ * (iteratively) and writes
+ *     rgb [rows*width*3] float : (1/spp_total) * sum over samples and diffuse hits of f*adj  (main.cpp:88)
+ *     nhit[rows*width]   uint32: number of Hitpoints of the pixel (may be NULL)
+ *     counters[CGRT_NCOUNTERS] uint64: totals, ADDED to the existing values (may be NULL)
+ * rgb, nhit and counters are DEVICE pointers on the scene's device; the launch is asynchronous on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream).  Arithmetic is fp64 on the device; the only fp32
+ * rounding is the final store. */
+int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,
+                    uint32_t *nhit, uint64_t *counters, void *stream);
+
+/* Convenience form with HOST output buffers: allocates device scratch, runs, synchronises and copies back
+ * (counters are overwritten, not added to). */
+int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,
+                         uint32_t *nhit, uint64_t *counters);
+
+/* Function-level probe used by parity tests: objs[obj]->intersect(org, dir, len, normal) for n rays on the
+ * device (host pointers; keys: per-ray stream key for Bezier draws, may be NULL). */
+int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const double *dir3, const uint64_t *keys,
+                        int n, int32_t *hit, double *len, double *normal3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGRT_H */
