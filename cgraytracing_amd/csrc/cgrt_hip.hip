@@ -874,4 +874,21 @@ int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const 
     return CGRT_OK;
 }
 
+int cgrt_lens_samples(uint64_t seed, const int64_t *pixel, const int32_t *sample, int n, double radius, double *out3) {
+    if (n < 0 || (n > 0 && (!pixel || !sample || !out3))) return fail(CGRT_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; i++) {
+        Stream rs{stream_key(seed, (uint64_t)pixel[i], (uint64_t)sample[i], 0), 0};
+        double sx, sy;
+        while (true) {
+            sx = rs.u01() * 2.0 - 1;
+            sy = rs.u01() * 2.0 - 1;
+            if (sx * sx + sy * sy < 1) break;
+        }
+        out3[3 * i] = sx * radius;
+        out3[3 * i + 1] = sy * radius;
+        out3[3 * i + 2] = 0 * radius;
+    }
+    return CGRT_OK;
+}
+
 }  // extern "C"

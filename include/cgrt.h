@@ -155,6 +155,11 @@ int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt
 int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const double *dir3, const uint64_t *keys,
                         int n, int32_t *hit, double *len, double *normal3);
 
+/* Host evaluation of the lens stream (cgrt_rng.hpp, the same inline code the kernel runs): writes
+ * uniform_sampling_circle(radius) (sampling.h:35-43) for n (pixel, sample) pairs as 3 doubles each.  Lets CPU-only
+ * tests pin the stream against the reference's sampler without a GPU. */
+int cgrt_lens_samples(uint64_t seed, const int64_t *pixel, const int32_t *sample, int n, double radius, double *out3);
+
 #ifdef __cplusplus
 }
 #endif

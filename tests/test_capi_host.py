@@ -1,0 +1,125 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cgrt.h declares; host-side prerequisites
+(mesh loaders, bump mesh, tree build, lens stream) of the PRODUCT match the golden vectors.  No compute calls."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, GOLD)
+import make_golden  # noqa: E402
+
+META = json.load(open(os.path.join(GOLD, "trace_meta.json")))
+
+
+def test_library_exports_every_declared_symbol():
+    from cgraytracing_amd import _capi
+    hdr = open(os.path.join(ROOT, "include", "cgrt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cgrt_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 17
+    lib = C.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libcgrt.so does not export %s" % name
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    assert _capi.lib().cgrt_version() == 100
+
+
+def test_struct_layouts_match_header():
+    from cgraytracing_amd import _capi
+    assert C.sizeof(_capi.Camera) == 48
+    assert C.sizeof(_capi.Grid) == 56  # 12 x int32 + uint64
+    assert C.sizeof(_capi.SceneStats) == 8 * 4 + 4 * 8
+
+
+def test_error_reporting_without_gpu_or_bad_args():
+    import cgraytracing_amd as cg
+    from cgraytracing_amd import _capi
+    L = _capi.lib()
+    assert L.cgrt_scene_create(None) == -1 and b"null" in L.cgrt_last_error()
+    with pytest.raises(ValueError):
+        cg.Bezier([(0, 0, 1)] * 7, (0, 0, 0), (1, 1, 1))
+    s = cg.Scene(scenes.scene_c1(), commit=False)
+    # tracing an uncommitted scene is refused, never a crash or a silent CPU path
+    with pytest.raises(_capi.CgrtError) as e:
+        s.trace_grid_host(8, 8)
+    assert e.value.code == -1
+    # a plane that names an unknown texture id
+    h = s._h
+    d3 = (C.c_double * 3)(0, 1, 0)
+    assert L.cgrt_scene_add_plane(h, d3, d3, d3, 0.0, 0.0, 5) == -1
+    s.close()
+    big = cg.Scene([scenes.Sphere((0, 0, 30 + i), 1, (1, 1, 1)) for i in range(96)], commit=False)
+    assert L.cgrt_scene_add_sphere(big._h, d3, 1.0, d3, 0.0, 0.0) == -5  # CGRT_ERR_LIMIT
+    big.close()
+
+
+def test_malformed_mesh_is_io_error(tmp_path):
+    import cgraytracing_amd as cg
+    from cgraytracing_amd import _capi
+    p = tmp_path / "bad.txt"
+    p.write_text("begin\nvertex 0 0 0\nvertex 1 0 0\nend\n")
+    with pytest.raises(_capi.CgrtError) as e:
+        cg.Scene([cg.TriangleMesh(str(p), 1, (0, 0, 0), (1, 1, 1))], commit=False)
+    assert e.value.code == -2
+    empty = cg.Scene([cg.TriangleMesh(str(tmp_path / "missing.txt"), 1, (0, 0, 0), (1, 1, 1))], commit=False)
+    assert empty.stats()["n_triangles"] == 0
+    empty.close()
+
+
+@pytest.mark.parametrize("name", ["t0", "t1", "t2"])
+def test_product_loaders_and_tree_build_match_reference(name):
+    import cgraytracing_amd as cg
+    file, a, b, typ = make_golden.LOADER_CASES[name]
+    g = np.load(os.path.join(GOLD, "loader_%s.npz" % name))
+    m = cg.TriangleMesh(os.path.join(GOLD, "assets", file), a, b, (0.6, 0.7, 0.9), 0.8, 0.5, typ)
+    s = cg.Scene(scenes.planes() + [m], commit=False)
+    nodes, leaf, bbox, tris = s.tree_dump(0)
+    assert np.array_equal(tris, g["tris"])
+    assert np.array_equal(nodes, g["nodes"]) and np.array_equal(leaf, g["leaf"]) and np.array_equal(bbox, g["bbox"])
+    s.close()
+
+
+@pytest.mark.parametrize("case,key", [("bunny_glass_chess_64", "mesh_tree"), ("dragon_64", "mesh_tree"),
+                                      ("stone_bump_64x48", "bump_tree"), ("chess_bump_48x36", "bump_tree")])
+def test_product_tree_fingerprints(case, key):
+    import cgraytracing_amd as cg
+    mk = {c[0]: c[1] for c in make_golden.trace_cases()}[case]
+    s = cg.Scene(mk(), commit=False)
+    nodes, leaf, bbox, tris = s.tree_dump(0)
+    assert make_golden.fingerprint(nodes, leaf) == META[case][key]
+    if key == "bump_tree":
+        assert hashlib.sha256(tris.tobytes()).hexdigest() == META[case]["bump_tris_sha256"]
+    st = s.stats()
+    assert st["n_trees"] == 1 and st["n_nodes"] == len(nodes) and st["n_triangles"] == len(leaf)
+    s.close()
+
+
+def test_product_lens_stream_matches_reference():
+    from cgraytracing_amd import _capi
+    g = np.load(os.path.join(GOLD, "lens_samples.npz"))
+    pix = np.ascontiguousarray(g["pix"], np.int64)
+    smp = np.ascontiguousarray(g["smp"], np.int32)
+    out = np.zeros((len(pix), 3))
+    _capi.check(_capi.lib().cgrt_lens_samples(int(g["seed"]), pix.ctypes.data, smp.ctypes.data, len(pix), 1.5,
+                                              out.ctypes.data))
+    assert np.array_equal(out, g["out"])
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped path must not import, link or fall back to anything under oracle/."""
+    pk = os.path.join(ROOT, "cgraytracing_amd")
+    for dp, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hpp", ".hip")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "liborc" not in txt and "oracle/" not in txt.replace("oracle/).", ""), os.path.join(dp, f)
+                assert "backends" not in txt

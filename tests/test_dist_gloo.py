@@ -1,0 +1,86 @@
+"""CPU, world_size 2 (gloo): the row sharding, gather and un-permute of cgraytracing_amd.dist, with the
+kernel launch replaced by a closed-form 'image' of the global row/column so that any mis-mapped row shows."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cgraytracing_amd.dist import StripedRenderer, assemble, global_row, local_rows
+
+
+def _pattern(rows_global, W):
+    r = torch.as_tensor(rows_global, dtype=torch.float32)[:, None, None]
+    c = torch.arange(W, dtype=torch.float32)[None, :, None]
+    ch = torch.arange(3, dtype=torch.float32)[None, None, :]
+    return r * 1000.0 + c + ch * 0.25
+
+
+def _worker(rank, world, port, W, H, S, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def render_local(rows, stripe):
+            s_rows, s_rank, s_n = stripe
+            gr = [global_row(j, s_rows, s_rank, s_n) for j in range(rows)]
+            img = _pattern(gr, W)
+            img[torch.as_tensor(gr) >= H] = 0  # rows past the image are left zero, like the kernel
+            return img.contiguous()
+
+        sr = StripedRenderer(W, H, stripe_rows=S, render_local=render_local)
+        assert sr.nranks == world and sr.rows_local == local_rows(H, S, rank, world)
+        for _ in range(2):  # twice: the gather buffer is reused
+            frame = sr.frame()
+        if rank == 0:
+            q.put(frame.numpy())
+        else:
+            assert frame is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("W,H,S", [(16, 64, 8), (5, 37, 8), (8, 48, 16)])
+def test_striped_gather_world2(W, H, S):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, W, H, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _pattern(list(range(H)), W).numpy()
+    assert frame.shape == (H, W, 3)
+    assert np.array_equal(frame, want)
+
+
+def test_stripe_mapping_is_a_partition():
+    for H, S, N in [(1080, 8, 8), (1080, 16, 4), (37, 8, 2), (4096, 16, 8), (8, 8, 8)]:
+        seen = []
+        for r in range(N):
+            rows = local_rows(H, S, r, N)
+            assert rows % S == 0
+            seen += [global_row(j, S, r, N) for j in range(rows)]
+        inside = sorted(g for g in seen if g < H)
+        assert inside == list(range(H)), (H, S, N)
+        assert len(set(seen)) == len(seen)
+
+
+def test_assemble_single_rank_is_identity():
+    x = torch.arange(2 * 3 * 4 * 3, dtype=torch.float32).reshape(1, 6, 4, 3)
+    assert torch.equal(assemble(x, 5, 8, 1), x[0][:5])
