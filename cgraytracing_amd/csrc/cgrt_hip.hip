@@ -226,6 +226,142 @@ __device__ __forceinline__ bool texture_color(const TexRec &t, const uint8_t *__
     return true;
 }
 
+
+// =====================================================================================================
+// Bezier surface of revolution: Bezier::intersect and helpers (bezier.h:30-40,72-290)
+// =====================================================================================================
+// The structure is the reference's: bounding-box reject; 10 Newton solves on (t,u,theta) from random starts
+// (u ~ U(0,1), t = 20 + 10 U(0,1), theta = atan(px/pz)); stale inverse reuse and a random jitter when the
+// Jacobian is singular; nearest accepted root wins; the cap-disc override that ignores the Newton flag.
+// Random draws come from the ray's keyed stream (cgrt_rng.hpp) in the reference's draw order.
+// pow(x, k) for the integer k <= 5 that occur is evaluated as a double-double product rounded once, which is the
+// correctly rounded power in all but near-tie cases -- the closest device analogue of libm's pow.
+__device__ const double kCni[7][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0},
+                                      {1, 3, 3, 1, 0, 0, 0}, {1, 4, 6, 4, 1, 0, 0}, {1, 5, 10, 10, 5, 1, 0},
+                                      {1, 6, 15, 20, 15, 6, 1}};  // bezier.h:17-23
+
+__device__ __forceinline__ double ipow_dd(double x, int k) {
+    if (k <= 0) return 1.0;
+    if (k == 1) return x;
+    double hi = x * x;
+    if (k == 2) return hi;
+    double lo = fma(x, x, -hi);
+    for (int j = 2; j < k; j++) {
+        const double p = hi * x;
+        const double e = fma(hi, x, -p);
+        const double l = lo * x + e;
+        const double s = p + l;
+        lo = l - (s - p);
+        hi = s;
+    }
+    return hi;
+}
+// bezier.h:30-40
+__device__ __forceinline__ double bern(int n, int i, double t) {
+    if (i > n || i < 0) return 0;
+    return kCni[n][i] * ipow_dd(1 - t, n - i) * ipow_dd(t, i);
+}
+__device__ __forceinline__ double dbern(int n, int i, double t) {
+    return bern(n - 1, i - 1, t) * (double)i - bern(n - 1, i, t) * (double)(n - i);
+}
+__device__ __forceinline__ V3 bez_value(const BezierRec &b, double u) {  // valueP, bezier.h:127-134
+    V3 r = mk(0, 0, 0);
+    const int n = b.ncp;
+    for (int i = 0; i < n; i++) r = r + ld3(b.cp[i]) * bern(n - 1, i, u);
+    return r;
+}
+__device__ __forceinline__ V3 bez_grad(const BezierRec &b, double u) {  // gradP, bezier.h:135-142
+    V3 r = mk(0, 0, 0);
+    const int n = b.ncp;
+    for (int i = 0; i < n; i++) r = r + ld3(b.cp[i]) * dbern(n - 1, i, u);
+    return r;
+}
+// bezier.h:72-126: any face crossing inside the grown rectangle with 0 < t < 1e10
+__device__ __forceinline__ bool bez_box(const BezierRec &b, V3 o, V3 d) {
+    const double xmin = b.box[0], xmax = b.box[1], ymin = b.box[2], ymax = b.box[3], zmin = b.box[4], zmax = b.box[5];
+    const double e = 1e-4;
+    bool flag = false;
+    double t;
+    V3 p;
+    t = (xmax - o.x) / d.x; p = o + d * t;
+    flag |= (t > 0 && p.y >= ymin - e && p.y <= ymax + e && p.z >= zmin - e && p.z <= zmax + e && t < kInf);
+    t = (xmin - o.x) / d.x; p = o + d * t;
+    flag |= (t > 0 && p.y >= ymin - e && p.y <= ymax + e && p.z >= zmin - e && p.z <= zmax + e && t < kInf);
+    t = (ymax - o.y) / d.y; p = o + d * t;
+    flag |= (t > 0 && p.x >= xmin - e && p.x <= xmax + e && p.z >= zmin - e && p.z <= zmax + e && t < kInf);
+    t = (ymin - o.y) / d.y; p = o + d * t;
+    flag |= (t > 0 && p.x >= xmin - e && p.x <= xmax + e && p.z >= zmin - e && p.z <= zmax + e && t < kInf);
+    t = (zmax - o.z) / d.z; p = o + d * t;
+    flag |= (t > 0 && p.x >= xmin - e && p.x <= xmax + e && p.y >= ymin - e && p.y <= ymax + e && t < kInf);
+    t = (zmin - o.z) / d.z; p = o + d * t;
+    flag |= (t > 0 && p.x >= xmin - e && p.x <= xmax + e && p.y >= ymin - e && p.y <= ymax + e && t < kInf);
+    return flag;
+}
+
+// Returns the Newton flag; len / n are written exactly as the reference writes them (n only when touched).
+__device__ bool bezier_intersect(const BezierRec &b, V3 pos, double cap_r, V3 o, V3 d, Stream rs, double &len, V3 &n) {
+    if (!bez_box(b, o, d)) return false;
+    bool flag = false;
+    len = kInf;
+    for (int k = 0; k < 10; k++) {  // num_of_samples_newton, bezier.h:27
+        const double u0 = rs.u01();
+        const double t0 = 20 + 10 * rs.u01();
+        V3 pt = o + d * t0;
+        pt = pt - pos;
+        const double th0 = (pt.z < 0) ? 3.14159265 + atan(pt.x / pt.z) : atan(pt.x / pt.z);  // bezier.h:243-247
+        // newtonMethod, bezier.h:163-214.  res = (t, u, theta)
+        V3 res = mk(t0, u0, th0);
+        V3 iD = mk(0, 0, 0), iE = mk(0, 0, 0), iF = mk(0, 0, 0);  // inverse columns, stale across singular steps
+        V3 P = bez_value(b, res.y);
+        double sn = sin(res.z), cs = cos(res.z);
+        V3 fv = ((o + d * res.x) - pos) - mk(P.z * sn, P.y, P.z * cs);  // funcValue, bezier.h:144-149
+        int counter = 0;
+        while (sqrt(fv.x * fv.x + fv.y * fv.y + fv.z * fv.z) > 1e-6 && counter < 100) {
+            counter++;
+            const V3 dP = bez_grad(b, res.y);
+            // gradValue, bezier.h:150-162
+            const V3 A = d;
+            const V3 B = mk(-sn * dP.z, -dP.y, -cs * dP.z);
+            const V3 C = mk(-cs * P.z, 0, sn * P.z);
+            const double dt = det3(A, B, C);  // inv(), vec3.h:103-119
+            if (dt < 1e-4 && dt > -1e-4) {
+                // bezier.h:183: Vec3(u(),u(),u()) evaluates right to left under g++
+                const double uz = rs.u01(), uy = rs.u01(), ux = rs.u01();
+                res = mk(res.x + ux * 0.2 - 0.1, res.y + uy * 0.2 - 0.1, res.z + uz * 0.2 - 0.1);
+            } else {
+                iD = mk((B.y * C.z - B.z * C.y) / dt, (C.y * A.z - C.z * A.y) / dt, (A.y * B.z - A.z * B.y) / dt);
+                iE = mk((C.x * B.z - C.z * B.x) / dt, (A.x * C.z - A.z * C.x) / dt, (B.x * A.z - B.z * A.x) / dt);
+                iF = mk((B.x * C.y - C.x * B.y) / dt, (C.x * A.y - C.y * A.x) / dt, (A.x * B.y - A.y * B.x) / dt);
+            }
+            const V3 step = (iD * fv.x + iE * fv.y) + iF * fv.z;  // matrixVectorProduct, vec3.h:99-101
+            res = res - step;
+            P = bez_value(b, res.y);
+            sn = sin(res.z);
+            cs = cos(res.z);
+            fv = ((o + d * res.x) - pos) - mk(P.z * sn, P.y, P.z * cs);
+        }
+        if (sqrt(fv.x * fv.x + fv.y * fv.y + fv.z * fv.z) < 1e-4 && res.x > 0 && res.y <= 1 && res.y >= 0) {
+            if (res.x < len) {
+                len = res.x;
+                const V3 rp = normalized(bez_grad(b, res.y));  // normalvec, bezier.h:215-224
+                n = mk(rp.y * sn, -rp.z, rp.y * cs);
+                flag = true;
+            }
+        }
+    }
+    n = (dot(n, d) < 0) ? n : -n;  // bezier.h:272
+    double newt = b.box[3] - o.y;  // ymax - rayorig.y, bezier.h:273-281
+    if (newt > 0.1) {
+        newt = newt / d.y;
+        const V3 np = o + d * newt;
+        if ((np.x - pos.x) * (np.x - pos.x) + (np.z - pos.z) * (np.z - pos.z) <= cap_r * cap_r) {
+            len = newt;
+            n = mk(0, 1, 0);
+        }
+    }
+    return flag;
+}
+
 // =====================================================================================================
 // nearest hit over objs (main.cpp:55-63) -- all lanes walk the LDS-resident list in lockstep
 // =====================================================================================================
@@ -235,9 +371,17 @@ struct SceneHit {
     V3 n;    // geometric normal as the object's intersect() returns it (before main.cpp:73-76)
 };
 
-template <bool TREES, bool STATS>
+// identifies a ray for the keyed Bezier stream: stream_key(seed, pixel, sample, (path << 16) | (object + 1)),
+// or, for the function-level probe, an explicit key
+struct RayKey {
+    uint64_t seed, pixel;
+    uint32_t sample, path;
+    bool explicit_key;
+};
+
+template <bool TREES, bool BEZ, bool STATS>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
-                                                    V3 o, V3 d, uint32_t &n_node, uint32_t &n_tri) {
+                                                    V3 o, V3 d, const RayKey &rk, uint32_t &n_node, uint32_t &n_tri) {
     SceneHit best;
     best.t = kInf;  // `nearest = INF`, main.cpp:54
     best.id = -1;
@@ -307,6 +451,22 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 best.n = nrm;
                 nsrc = 1;
             }
+        } else if (BEZ && kind == KIND_BEZIER) {
+            const BezierRec &bz = sc.beziers[__builtin_amdgcn_readfirstlane(ob.aux)];
+            Stream rs{rk.explicit_key ? rk.seed
+                                      : stream_key(rk.seed, rk.pixel, rk.sample,
+                                                   ((uint64_t)rk.path << 16) | (uint64_t)(i + 1)),
+                      0};
+            double len = 0;
+            V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
+            if (bezier_intersect(bz, ld3(ob.a), ob.b[0], o, d, rs, len, nrm)) {
+                if (len < best.t) {
+                    best.t = len;
+                    best.id = i;
+                    best.n = nrm;
+                    nsrc = 1;
+                }
+            }
         }
     }
     if (best.id >= 0 && nsrc == 0) {
@@ -325,7 +485,7 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
     uint32_t path;
 };
 
-template <bool TREES, bool DOF, bool STATS>
+template <bool TREES, bool BEZ, bool DOF, bool STATS>
 __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters) {
@@ -400,7 +560,8 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
         wave_iters++;
         if (have) {
             my_rays++;
-            const SceneHit hit = intersect_scene<TREES, STATS>(lobjs, sc.n_objs, sc, o, d, my_nodes, my_tris);
+            const RayKey rk{g.seed, pixel_id, (uint32_t)(g.sample_offset + s - 1), path, false};
+            const SceneHit hit = intersect_scene<TREES, BEZ, STATS>(lobjs, sc.n_objs, sc, o, d, rk, my_nodes, my_tris);
             have = false;
             if (hit.id >= 0) {
                 const ObjRec &ob = lobjs[hit.id];
@@ -519,14 +680,16 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
 
 // function-level probe: one object, n rays (cgrt_intersect_rays)
 __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__restrict__ org,
-                                      const double *__restrict__ dir, int n, int32_t *__restrict__ hit,
+                                      const double *__restrict__ dir, const unsigned long long *__restrict__ keys,
+                                      int n, int32_t *__restrict__ hit,
                                       double *__restrict__ len, double *__restrict__ nrm) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t a = 0, b = 0;
     const V3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
     DeviceScene one = sc;
-    SceneHit h = intersect_scene<true, false>(sc.objs + obj, 1, one, o, d, a, b);
+    const RayKey rk{keys ? keys[i] : 0ull, 0, 0, 1, true};
+    SceneHit h = intersect_scene<true, true, false>(sc.objs + obj, 1, one, o, d, rk, a, b);
     hit[i] = h.id >= 0 ? 1 : 0;
     len[i] = h.t;
     nrm[3 * i] = h.n.x;
@@ -647,7 +810,6 @@ int cgrt_scene_add_bezier(cgrt_scene *s, const double *cp3, int ncp, const doubl
 
 int cgrt_scene_commit(cgrt_scene *s, int device) {
     NEED_OPEN(s);
-    if (!s->host.beziers.empty()) return fail(CGRT_ERR_UNSUPPORTED, "Bezier objects are not yet traced on the device");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(CGRT_ERR_DEVICE, "no such HIP device");
@@ -799,15 +961,17 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const size_t lds = (size_t)kMaxObjs * sizeof(ObjRec) + (size_t)kTileH * kTileW * 3 * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
-    const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0;
+    const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0, bez = s->dev.has_bezier != 0;
     const bool stats = (grid->flags & 1) != 0;
-#define LAUNCH(T, D, S) \
-    hipLaunchKernelGGL((trace_grid_kernel<T, D, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
-    if (trees) {
-        if (dof) { if (stats) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
-        else     { if (stats) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+#define LAUNCH(T, B, D, S) \
+    hipLaunchKernelGGL((trace_grid_kernel<T, B, D, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
+    if (bez) {  // Bezier scenes share one variant pair (tree code included; it is skipped when there is no tree)
+        if (dof) LAUNCH(true, true, true, false); else LAUNCH(true, true, false, false);
+    } else if (trees) {
+        if (dof) { if (stats) LAUNCH(true, false, true, true); else LAUNCH(true, false, true, false); }
+        else     { if (stats) LAUNCH(true, false, false, true); else LAUNCH(true, false, false, false); }
     } else {
-        if (dof) LAUNCH(false, true, false); else LAUNCH(false, false, false);
+        if (dof) LAUNCH(false, false, true, false); else LAUNCH(false, false, false, false);
     }
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
@@ -848,7 +1012,6 @@ int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt
 
 int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const double *dir3, const uint64_t *keys,
                         int n, int32_t *hit, double *len, double *normal3) {
-    (void)keys;
     if (!s || !s->committed) return fail(CGRT_ERR_INVALID, "scene not committed");
     if (obj < 0 || obj >= s->dev.n_objs || n < 0 || !org3 || !dir3 || !hit || !len || !normal3)
         return fail(CGRT_ERR_INVALID, "bad argument");
@@ -863,14 +1026,20 @@ int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const 
     HIP_TRY(hipMalloc((void **)&d_hit, (size_t)n * 4));
     HIP_TRY(hipMemcpy(d_o, org3, (size_t)n * 24, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir3, (size_t)n * 24, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(intersect_rays_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, obj, d_o, d_d, n, d_hit,
-                       d_len, d_n);
+    unsigned long long *d_keys = nullptr;
+    if (keys) {
+        HIP_TRY(hipMalloc((void **)&d_keys, (size_t)n * 8));
+        HIP_TRY(hipMemcpy(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(intersect_rays_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, obj, d_o, d_d, d_keys, n,
+                       d_hit, d_len, d_n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(normal3, d_n, (size_t)n * 24, hipMemcpyDeviceToHost));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_len); (void)hipFree(d_n); (void)hipFree(d_hit);
+    if (d_keys) (void)hipFree(d_keys);
     return CGRT_OK;
 }
 
