@@ -141,3 +141,27 @@ def test_stripes_and_sample_ranges_compose(gpu_ready):
     top = sc.trace_grid_host(W, H, spp, cam, 5, 99, rows=40, row_offset=43)
     assert np.array_equal(top["rgb"], full["rgb"][43:])
     sc.close()
+
+
+def test_cpp_host_program_dropin(gpu_ready, orc, tmp_path):
+    """examples/main_dropin.cpp (reference-style main() over include/cgrt_host.hpp, plain g++) end to end:
+    C2 with the thin lens against the oracle, and a file-loaded glass mesh against the REFERENCE's golden."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cgraytracing_amd", "cgrt_main")
+    assert os.path.exists(exe), "build it with make -C cgraytracing_amd/csrc all"
+    raw = str(tmp_path / "c2.f32")
+    out = subprocess.run([exe, "--scene", "c2", "--width", "96", "--height", "54", "--spp", "4", "--dof", "--raw", raw],
+                         capture_output=True, text=True, check=True).stdout
+    o = BackendScene(orc, scenes.scene_c2())
+    want = o.trace_grid(scenes.cam_dof(), 96, 54, 4, 5, seed=12345)
+    got = np.fromfile(raw, np.float32).reshape(54, 96, 3)
+    assert np.array_equal(got, to_acc32(want["acc_sum"], 4))
+    assert "rays: %d " % want["nrays"] in out
+    raw2 = str(tmp_path / "mesh.f32")
+    subprocess.run([exe, "--scene", "planes", "--mesh", os.path.join(GOLD, "assets", "mesh_t0.txt"), "0", "--width", "48",
+                    "--height", "48", "--raw", raw2], capture_output=True, text=True, check=True)
+    g = np.load(os.path.join(GOLD, "loader_t0.npz"))
+    got2 = np.fromfile(raw2, np.float32).reshape(48, 48, 3)
+    assert np.array_equal(got2, to_acc32(g["acc_sum"], 1))
