@@ -107,14 +107,13 @@ def main():
     sr = StripedRenderer(W, Ht, stripe_rows=args.stripe_rows)
     rows_local = sr.rows_local
     out = torch.zeros((rows_local, W, 3), dtype=torch.float32, device=dev)
-    nhit = torch.zeros((rows_local, W), dtype=torch.int32, device=dev)
     kernel_events = []
 
     def render_local(rows, stripe, record=False):
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        scene.trace_grid(W, Ht, SPP, cam, DEPTH, SEED, rows=rows, stripe=stripe, out=out, nhit=nhit,
+        scene.trace_grid(W, Ht, SPP, cam, DEPTH, SEED, rows=rows, stripe=stripe, out=out, nhit=False,
                          counters=counters)
         if record:
             e1.record()

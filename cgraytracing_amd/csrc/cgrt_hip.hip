@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,6 +74,18 @@ struct GridParams {
 
 static constexpr int kTileW = 32, kTileH = 8, kThreads = 256;
 static constexpr int kMaxObjs = 96;  // top-level objects staged in LDS (12 KiB)
+// Pending refracted rays (main.cpp:157) of a lane, newest last:
+//   * a glass hit whose children are leaves of the recursion (depth_left == 2) keeps the refracted child in
+//     REGISTERS (it is consumed right after the reflected child, before any other push) -- in a full glass tree
+//     that is 8 of the 15 pushes;
+//   * the first two other levels live in LDS (2 x 10 doubles x 256 threads = 40 KiB per workgroup, layout
+//     [level][field][thread]: conflict-free 8-byte accesses);
+//   * a third level (three nested glass hits with all siblings waiting) spills to scratch memory.
+// 40 KiB + objs + tile keeps 3 workgroups = 3 waves/SIMD per CU, measured to be as fast as 4.
+static constexpr int kPendDoubles = 10;
+static constexpr int kLdsLevels = 2;
+static constexpr size_t kStackBytes = (size_t)kLdsLevels * kPendDoubles * kThreads * sizeof(double);
+static constexpr size_t kTileBytes = (size_t)8 * 32 * 3 * sizeof(float);
 
 // local row -> global row (cgrt.h: block-cyclic stripes)
 __device__ __forceinline__ int global_row(const GridParams &g, int j) {
@@ -371,11 +384,11 @@ struct SceneHit {
     V3 n;    // geometric normal as the object's intersect() returns it (before main.cpp:73-76)
 };
 
-// identifies a ray for the keyed Bezier stream: stream_key(seed, pixel, sample, (path << 16) | (object + 1)),
-// or, for the function-level probe, an explicit key
+// identifies a ray for the keyed Bezier stream: purpose_key(k_smp, (path << 16) | (object + 1)), or, for the
+// function-level probe, an explicit key
 struct RayKey {
-    uint64_t seed, pixel;
-    uint32_t sample, path;
+    uint64_t k;  // the sample's key k_smp (cgrt_rng.hpp), or the explicit stream key
+    uint32_t path;
     bool explicit_key;
 };
 
@@ -453,10 +466,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             }
         } else if (BEZ && kind == KIND_BEZIER) {
             const BezierRec &bz = sc.beziers[__builtin_amdgcn_readfirstlane(ob.aux)];
-            Stream rs{rk.explicit_key ? rk.seed
-                                      : stream_key(rk.seed, rk.pixel, rk.sample,
-                                                   ((uint64_t)rk.path << 16) | (uint64_t)(i + 1)),
-                      0};
+            Stream rs(rk.explicit_key ? rk.k : purpose_key(rk.k, ((uint64_t)rk.path << 16) | (uint64_t)(i + 1)));
             double len = 0;
             V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
             if (bezier_intersect(bz, ld3(ob.a), ob.b[0], o, d, rs, len, nrm)) {
@@ -485,13 +495,17 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
     uint32_t path;
 };
 
-template <bool TREES, bool BEZ, bool DOF, bool STATS>
-__global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+// GLASS: the scene contains a transparent object, so refracted children can be pending; without it the
+// pending-ray storage (LDS levels, sibling registers) is compiled out and occupancy goes up.
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool STATS>
+__global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters) {
+    // LDS carve-up: [ pending-ray slot 0: kPendDoubles x 256 doubles | objs | output tile ]
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw);
-    float *ltile = reinterpret_cast<float *>(lds_raw + (size_t)kMaxObjs * sizeof(ObjRec));  // [kTileH][kTileW*3]
+    double *lstack = reinterpret_cast<double *>(lds_raw);  // [field][thread], conflict-free 8-byte accesses
+    float *ltile = reinterpret_cast<float *>(lds_raw + (GLASS ? kStackBytes : 0));
+    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? kStackBytes : 0) + kTileBytes);  // n_objs records
 
     // stage the primitive list in LDS (128 B records, copied as 16-byte pieces)
     {
@@ -518,12 +532,16 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
     const double py = (2.0 * ((double)h / g.H) - 1) * g.half_width * g.H / g.W;
     const V3 pdir = normalized(mk(px, py, 0) - camorg);
     const V3 pof = pdir * ((g.focus_plane - camorg.z) / pdir.z) + camorg;
-    const uint64_t pixel_id = (uint64_t)h * (uint64_t)g.W + (uint64_t)w;
+    const uint64_t k_pix = pixel_key(g.seed, (uint64_t)h * (uint64_t)g.W + (uint64_t)w);
+    uint64_t k_smp = 0;  // key of the sample whose ray tree this lane is tracing
 
     double acc_r = 0, acc_g = 0, acc_b = 0;
     uint32_t my_hits = 0, my_rays = 0, my_nodes = 0, my_tris = 0, wave_iters = 0;
 
-    Pending stack[kMaxDepth - 1];
+    Pending deep[2];   // third stack level (scratch; indexed dynamically so that it stays out of registers)
+    Pending sib;       // refracted sibling of a leaf-level glass hit (registers)
+    bool sib_valid = false;
+    double *lslot = lstack + threadIdx.x;
     int sp = 0;
     int s = 0;  // next sample to start
     bool have = false;
@@ -535,8 +553,9 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
         if (!have) {
             if (live && s < g.spp) {
                 // start the next sample of this lane's pixel (main.cpp:204-209)
+                k_smp = sample_key(k_pix, (uint64_t)(g.sample_offset + s));
                 if (DOF) {
-                    Stream rs{stream_key(g.seed, pixel_id, (uint64_t)(g.sample_offset + s), 0), 0};
+                    Stream rs(k_smp);  // purpose 0: the lens stream's key is the sample key
                     double sx, sy;
                     while (true) {  // uniform_sampling_circle, sampling.h:35-43
                         sx = rs.u01() * 2.0 - 1;
@@ -560,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
         wave_iters++;
         if (have) {
             my_rays++;
-            const RayKey rk{g.seed, pixel_id, (uint32_t)(g.sample_offset + s - 1), path, false};
+            const RayKey rk{k_smp, path, false};
             const SceneHit hit = intersect_scene<TREES, BEZ, STATS>(lobjs, sc.n_objs, sc, o, d, rk, my_nodes, my_tris);
             have = false;
             if (hit.id >= 0) {
@@ -596,7 +615,7 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
                         depth_left--;
                         path = path * 2;
                         have = true;
-                    } else {
+                    } else if (GLASS) {
                         // glass, main.cpp:135-157
                         const double nc = 1.0, nt = 1.33;
                         const double nnt = into ? nc / nt : nt / nc;
@@ -614,12 +633,27 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
                             const double c = 1 - (into ? -ddn : dot(refr_dir, n_old));
                             const double Re = R0 + (1 - R0) * c * c * c * c * c;
                             const V3 fa = mulv(f, adj);
-                            Pending &pe = stack[sp++];
+                            Pending pe;
                             pe.o = P - n * kEps;
                             pe.d = refr_dir;
                             pe.adj = fa * (1 - Re);
                             pe.depth_left = depth_left - 1;
                             pe.path = path * 2 + 1;
+                            if (depth_left == 2) {
+                                sib = pe;
+                                sib_valid = true;
+                            } else {
+                                if (sp < kLdsLevels) {
+                                    double *q = lslot + sp * (kPendDoubles * kThreads);
+                                    q[0 * kThreads] = pe.o.x; q[1 * kThreads] = pe.o.y; q[2 * kThreads] = pe.o.z;
+                                    q[3 * kThreads] = pe.d.x; q[4 * kThreads] = pe.d.y; q[5 * kThreads] = pe.d.z;
+                                    q[6 * kThreads] = pe.adj.x; q[7 * kThreads] = pe.adj.y; q[8 * kThreads] = pe.adj.z;
+                                    q[9 * kThreads] = __hiloint2double(pe.depth_left, (int)pe.path);
+                                } else {
+                                    deep[sp - kLdsLevels] = pe;
+                                }
+                                sp++;
+                            }
                             o = P + n * kEps;
                             d = refl_dir;
                             adj = fa * Re;
@@ -630,13 +664,33 @@ __global__ __launch_bounds__(kThreads) void trace_grid_kernel(DeviceScene sc, Gr
                     }
                 }
             }
-            if (!have && sp > 0) {
-                const Pending &pe = stack[--sp];
-                o = pe.o;
-                d = pe.d;
-                adj = pe.adj;
-                depth_left = pe.depth_left;
-                path = pe.path;
+            if (GLASS && !have && sib_valid) {
+                o = sib.o;
+                d = sib.d;
+                adj = sib.adj;
+                depth_left = sib.depth_left;
+                path = sib.path;
+                sib_valid = false;
+                have = true;
+            }
+            if (GLASS && !have && sp > 0) {
+                --sp;
+                if (sp < kLdsLevels) {
+                    const double *q = lslot + sp * (kPendDoubles * kThreads);
+                    o = mk(q[0 * kThreads], q[1 * kThreads], q[2 * kThreads]);
+                    d = mk(q[3 * kThreads], q[4 * kThreads], q[5 * kThreads]);
+                    adj = mk(q[6 * kThreads], q[7 * kThreads], q[8 * kThreads]);
+                    const double meta = q[9 * kThreads];
+                    depth_left = __double2hiint(meta);
+                    path = (uint32_t)__double2loint(meta);
+                } else {
+                    const Pending &pe = deep[sp - kLdsLevels];
+                    o = pe.o;
+                    d = pe.d;
+                    adj = pe.adj;
+                    depth_left = pe.depth_left;
+                    path = pe.path;
+                }
                 have = true;
             }
         }
@@ -688,7 +742,7 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     uint32_t a = 0, b = 0;
     const V3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
     DeviceScene one = sc;
-    const RayKey rk{keys ? keys[i] : 0ull, 0, 0, 1, true};
+    const RayKey rk{keys ? keys[i] : 0ull, 1, true};
     SceneHit h = intersect_scene<true, true, false>(sc.objs + obj, 1, one, o, d, rk, a, b);
     hit[i] = h.id >= 0 ? 1 : 0;
     len[i] = h.t;
@@ -864,8 +918,11 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     d.has_mesh = trees.empty() ? 0 : 1;
     d.has_bezier = H.beziers.empty() ? 0 : 1;
     d.all_spheres = 1;
-    for (auto &o : H.objs)
+    d.has_glass = 0;
+    for (auto &o : H.objs) {
         if (o.kind != KIND_SPHERE) d.all_spheres = 0;
+        if (!(o.transp < kEps)) d.has_glass = 1;  // main.cpp:129: the glass branch is `!(transparency < eps)`
+    }
     s->dev = d;
     s->committed = true;
     return CGRT_OK;
@@ -958,21 +1015,29 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
 
     const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
     const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
-    const size_t lds = (size_t)kMaxObjs * sizeof(ObjRec) + (size_t)kTileH * kTileW * 3 * sizeof(float);
+    size_t lds = kStackBytes + kTileBytes + (size_t)s->dev.n_objs * sizeof(ObjRec);
+    if (const char *e = getenv("CGRT_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiments only
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
     const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0, bez = s->dev.has_bezier != 0;
-    const bool stats = (grid->flags & 1) != 0;
-#define LAUNCH(T, B, D, S) \
-    hipLaunchKernelGGL((trace_grid_kernel<T, B, D, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
-    if (bez) {  // Bezier scenes share one variant pair (tree code included; it is skipped when there is no tree)
-        if (dof) LAUNCH(true, true, true, false); else LAUNCH(true, true, false, false);
+    const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
+    const bool stats = (grid->flags & 1) != 0 && trees && !bez;
+    if (!glass) lds -= kStackBytes;
+#define LAUNCH(T, B, D, G, S) \
+    hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
+#define LAUNCH_DG(T, B, S)                                         \
+    do {                                                           \
+        if (dof) { if (glass) LAUNCH(T, B, true, true, S); else LAUNCH(T, B, true, false, S); }   \
+        else     { if (glass) LAUNCH(T, B, false, true, S); else LAUNCH(T, B, false, false, S); } \
+    } while (0)
+    if (bez) {  // Bezier scenes share the tree-capable variants (the tree code is skipped when there is no tree)
+        LAUNCH_DG(true, true, false);
     } else if (trees) {
-        if (dof) { if (stats) LAUNCH(true, false, true, true); else LAUNCH(true, false, true, false); }
-        else     { if (stats) LAUNCH(true, false, false, true); else LAUNCH(true, false, false, false); }
+        if (stats) LAUNCH_DG(true, false, true); else LAUNCH_DG(true, false, false);
     } else {
-        if (dof) LAUNCH(false, false, true, false); else LAUNCH(false, false, false, false);
+        LAUNCH_DG(false, false, false);
     }
+#undef LAUNCH_DG
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return CGRT_OK;
@@ -1046,7 +1111,7 @@ int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const 
 int cgrt_lens_samples(uint64_t seed, const int64_t *pixel, const int32_t *sample, int n, double radius, double *out3) {
     if (n < 0 || (n > 0 && (!pixel || !sample || !out3))) return fail(CGRT_ERR_INVALID, "bad argument");
     for (int i = 0; i < n; i++) {
-        Stream rs{stream_key(seed, (uint64_t)pixel[i], (uint64_t)sample[i], 0), 0};
+        Stream rs(stream_key(seed, (uint64_t)pixel[i], (uint64_t)sample[i], 0));
         double sx, sy;
         while (true) {
             sx = rs.u01() * 2.0 - 1;

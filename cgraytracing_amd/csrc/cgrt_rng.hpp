@@ -4,9 +4,15 @@
 // neither reproducible across implementations nor usable from 10^5 concurrent lanes.  Every draw here is a pure
 // function of (seed, pixel, sample, purpose, draw index):
 //
-//   key  = fin(fin(fin(fin(seed+G)+pixel+G)+sample+G)+purpose+G)        G = 0x9E3779B97F4A7C15 (splitmix64)
-//   r31  = fin(key + (i+1)*G) >> 33                                       31 random bits, like glibc rand()
-//   u01  = (double)r31 / 2147483647.0                                     same expression as sampling.h:32
+//   k_pix = fin(fin(seed+G) + pixel + G)          once per pixel        G = 0x9E3779B97F4A7C15 (splitmix64)
+//   k_smp = fin(k_pix + sample + G)               once per sample; this IS the lens stream's key (purpose 0)
+//   key   = fin(k_smp + purpose + G)              other purposes (>= 1)
+//   r31   = fin(key + (i+1)*G) >> 33              31 random bits, like glibc rand(); i.e. splitmix64 seeded with key
+//   u01   = (double)r31 / 2147483647.0            same value as sampling.h:32's rand()/RAND_MAX
+//
+// The division by RAND_MAX is evaluated as q0 = r*rc, q = fma(fma(-q0, D, r), rc, q0) with rc = fl(1/D): verified
+// exhaustively (all 2^31 inputs, tests/test_rng_division.py runs a sample; DESIGN.md has the full-sweep program) to
+// equal the correctly rounded quotient, at 3 instructions instead of the ~15 of an IEEE divide.
 //
 // pixel = h*W + w on the GLOBAL image, so a render is independent of how rows are sharded over GPUs.
 // purpose = 0 for the lens; (path_code << 16) | (object index + 1) for Bezier draws, where path_code is the ray's
@@ -14,6 +20,7 @@
 #ifndef CGRT_RNG_HPP
 #define CGRT_RNG_HPP
 #include <stdint.h>
+#include <cmath>
 
 #if defined(__HIPCC__)
 #define CGRT_HD __host__ __device__ __forceinline__
@@ -30,19 +37,34 @@ CGRT_HD uint64_t fin64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-CGRT_HD uint64_t stream_key(uint64_t seed, uint64_t pixel, uint64_t sample, uint64_t purpose) {
-    uint64_t k = fin64(seed + kGolden);
-    k = fin64(k + pixel + kGolden);
-    k = fin64(k + sample + kGolden);
-    k = fin64(k + purpose + kGolden);
-    return k;
+CGRT_HD uint64_t pixel_key(uint64_t seed, uint64_t pixel) { return fin64(fin64(seed + kGolden) + pixel + kGolden); }
+CGRT_HD uint64_t sample_key(uint64_t k_pix, uint64_t sample) { return fin64(k_pix + sample + kGolden); }
+CGRT_HD uint64_t purpose_key(uint64_t k_smp, uint64_t purpose) {
+    return purpose ? fin64(k_smp + purpose + kGolden) : k_smp;
 }
-CGRT_HD uint32_t rand31(uint64_t key, uint32_t i) { return (uint32_t)(fin64(key + (uint64_t)(i + 1u) * kGolden) >> 33); }
+CGRT_HD uint64_t stream_key(uint64_t seed, uint64_t pixel, uint64_t sample, uint64_t purpose) {
+    return purpose_key(sample_key(pixel_key(seed, pixel), sample), purpose);
+}
+// (double)r / 2147483647.0, correctly rounded, for integer 0 <= r < 2^31
+CGRT_HD double div_rand_max(uint32_t r) {
+    const double D = 2147483647.0, rc = 1.0 / 2147483647.0;
+    const double x = (double)r;
+    const double q0 = x * rc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(__builtin_fma(-q0, D, x), rc, q0);
+#else
+    return std::fma(std::fma(-q0, D, x), rc, q0);
+#endif
+}
 
 struct Stream {
-    uint64_t key;
-    uint32_t i;
-    CGRT_HD double u01() { return (double)rand31(key, i++) / 2147483647.0; }
+    uint64_t state;  // key + i*G
+    CGRT_HD explicit Stream(uint64_t key) : state(key) {}
+    CGRT_HD uint32_t next31() {
+        state += kGolden;
+        return (uint32_t)(fin64(state) >> 33);
+    }
+    CGRT_HD double u01() { return div_rand_max(next31()); }
 };
 
 }  // namespace cgrt

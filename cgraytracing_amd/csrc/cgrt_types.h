@@ -92,7 +92,7 @@ struct DeviceScene {
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
     int32_t has_bezier;
     int32_t all_spheres; // fast path selector
-    int32_t pad;
+    int32_t has_glass;   // some object takes the refraction branch (main.cpp:135)
 };
 
 }  // namespace cgrt

@@ -119,13 +119,16 @@ class Scene:
             out = torch.zeros((rows, width, 3), dtype=torch.float32, device=dev)
         if nhit is None:
             nhit = torch.zeros((rows, width), dtype=torch.int32, device=dev)
+        elif nhit is False:  # skip the optional per-pixel hitpoint-count plane
+            nhit = None
         if counters is None:
             counters = torch.zeros((_capi.CGRT_NCOUNTERS,), dtype=torch.int64, device=dev)
         assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (rows, width, 3)
         cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
                               spp_total, 1 if stats else 0)
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-        check(self._L.cgrt_trace_grid(self._h, C.byref(cc), C.byref(g), out.data_ptr(), nhit.data_ptr(),
+        check(self._L.cgrt_trace_grid(self._h, C.byref(cc), C.byref(g), out.data_ptr(),
+                                      nhit.data_ptr() if nhit is not None else None,
                                       counters.data_ptr(), C.c_void_p(st)))
         return out, nhit, counters
 

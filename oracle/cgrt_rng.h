@@ -7,7 +7,7 @@
  * of this integer recipe in cgraytracing_amd/csrc/cgrt_rng.hpp; tests check
  * the two agree bit for bit.
  *
- * stream(K)[i] = splitmix64 finaliser of (K + (i+1)*GOLDEN) >> 33   (31 bits)
+ * stream(K)[i] = splitmix64 finaliser of (K + (i+1)*GOLDEN) >> 33   (31 bits; i.e. splitmix64 seeded with K)
  * u01          = (double)r31 / 2147483647.0      (RAND_MAX of glibc)
  */
 #ifndef CGRT_ORACLE_RNG_H
@@ -22,12 +22,15 @@ static inline uint64_t cgrt_fin64(uint64_t z) {
     return z ^ (z >> 31);
 }
 /* key derivation: a = pixel index (h*W+w on the GLOBAL image), b = sample index,
- * c = purpose tag (0 = lens; Bezier: (path_code << 16) | (object_order + 1)) */
+ * c = purpose tag (0 = lens; Bezier: (path_code << 16) | (object_order + 1), always >= 1).
+ *   k_pix = fin(fin(seed+G) + pixel + G)      once per pixel
+ *   k_smp = fin(k_pix + sample + G)           once per sample  = the lens stream's key (purpose 0)
+ *   key   = fin(k_smp + purpose + G)          purpose >= 1 */
 static inline uint64_t cgrt_key(uint64_t seed, uint64_t a, uint64_t b, uint64_t c) {
     uint64_t k = cgrt_fin64(seed + CGRT_GOLDEN);
     k = cgrt_fin64(k + a + CGRT_GOLDEN);
     k = cgrt_fin64(k + b + CGRT_GOLDEN);
-    k = cgrt_fin64(k + c + CGRT_GOLDEN);
+    if (c != 0) k = cgrt_fin64(k + c + CGRT_GOLDEN);
     return k;
 }
 static inline uint32_t cgrt_rand31(uint64_t key, uint32_t i) {

@@ -1,0 +1,56 @@
+"""Ad-hoc kernel timing probe (not a test): python tests/perf_probe.py [scene ...]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+
+import cgraytracing_amd as cg
+import scenes
+
+
+def run(name, objs, cam, W, H, spp, depth, reps=5, stats=False):
+    sc = cg.Scene(objs)
+    out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    nh = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    sc.trace_grid(W, H, spp, cam, depth, 12345, out=out, nhit=nh, counters=cnt, stats=stats)
+    torch.cuda.synchronize()
+    cnt.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sc.trace_grid(W, H, spp, cam, depth, 12345, out=out, nhit=nh, counters=cnt, stats=stats)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    c = cnt.cpu().numpy() / reps
+    rays = c[0]
+    print("%-28s %4dx%-4d spp%-3d d%d  %8.3f ms  %9.1f Mrays/s  rays/px/s %.3f  util %.3f  nodes/ray %.1f tris/ray %.1f"
+          % (name, W, H, spp, depth, ms, rays / ms / 1e3, rays / (W * H * spp), rays / max(1, 64 * c[2]),
+             c[3] / max(rays, 1), c[4] / max(rays, 1)), flush=True)
+    sc.close()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2"]
+    if "c2" in which:
+        run("c2 dof d5", scenes.scene_c2(), scenes.cam_dof(), 1920, 1080, 64, 5)
+        run("c2 pinhole d5", scenes.scene_c2(), scenes.cam_pinhole(), 1920, 1080, 64, 5)
+        run("c2 dof d1", scenes.scene_c2(), scenes.cam_dof(), 1920, 1080, 64, 1)
+        run("c2 pinhole d1", scenes.scene_c2(), scenes.cam_pinhole(), 1920, 1080, 64, 1)
+        run("c1 pinhole d1", scenes.scene_c1(), scenes.cam_pinhole(), 1920, 1080, 64, 1)
+    if "c3" in which:
+        run("c3 bunny glass dof", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 16, 5, reps=2, stats=True)
+        run("c3 bunny glass dof nostat", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 16, 5, reps=2)
+    if "c4" in which:
+        run("c4 dragon dof", scenes.scene_dragon(), scenes.cam_dof(), 2048, 2048, 4, 5, reps=2, stats=True)
+        run("c4 dragon dof nostat", scenes.scene_dragon(), scenes.cam_dof(), 2048, 2048, 4, 5, reps=2)
+    if "c5" in which:
+        tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+        run("c5 bump only", scenes.planes(tex), scenes.cam_dof(), 1024, 1024, 2, 5, reps=1, stats=True)
+        run("c5 bump+vase", scenes.scene_c5(tex), scenes.cam_dof(), 512, 512, 1, 5, reps=1)
+        run("vase only", scenes.planes() + [scenes.vase_bezier()], scenes.cam_dof(), 512, 512, 1, 5, reps=1)
