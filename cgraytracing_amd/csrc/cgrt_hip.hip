@@ -132,35 +132,45 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
     r.tri = -1;
     r.counter = 0;
     int i = 0;
-    while (i < nnodes) {
-        const NodeRec *nd = nodes + i;
-        if (STATS) n_node++;
-        double t1, t2, tn, tf;
-        t1 = (nd->lo[0] - o.x) * inv.x;
-        t2 = (nd->hi[0] - o.x) * inv.x;
-        tn = fmin(t1, t2);
-        tf = fmax(t1, t2);
-        t1 = (nd->lo[1] - o.y) * inv.y;
-        t2 = (nd->hi[1] - o.y) * inv.y;
-        tn = fmax(tn, fmin(t1, t2));
-        tf = fmin(tf, fmax(t1, t2));
-        t1 = (nd->lo[2] - o.z) * inv.z;
-        t2 = (nd->hi[2] - o.z) * inv.z;
-        tn = fmax(tn, fmin(t1, t2));
-        tf = fmin(tf, fmax(t1, t2));
-        const bool touch = (tf > 0.0) && (tn <= tf);
-        const int cnt = nd->tri_count;
-        if (!touch) {
-            i = nd->skip;
-            continue;
+    // "while-while" traversal: every lane first walks inner nodes until it stands on a leaf its ray touches
+    // (or runs out of nodes); only then does the wave scan leaves, so the ~800-instruction leaf scan runs once
+    // per leaf-visit round with many lanes active instead of once per node step with one or two.
+    while (true) {
+        int leaf_begin = 0, leaf_cnt_tris = -1;
+        while (i < nnodes) {
+            const NodeRec *nd = nodes + i;
+            if (STATS) n_node++;
+            double t1, t2, tn, tf;
+            t1 = (nd->lo[0] - o.x) * inv.x;
+            t2 = (nd->hi[0] - o.x) * inv.x;
+            tn = fmin(t1, t2);
+            tf = fmax(t1, t2);
+            t1 = (nd->lo[1] - o.y) * inv.y;
+            t2 = (nd->hi[1] - o.y) * inv.y;
+            tn = fmax(tn, fmin(t1, t2));
+            tf = fmin(tf, fmax(t1, t2));
+            t1 = (nd->lo[2] - o.z) * inv.z;
+            t2 = (nd->hi[2] - o.z) * inv.z;
+            tn = fmax(tn, fmin(t1, t2));
+            tf = fmin(tf, fmax(t1, t2));
+            const bool touch = (tf > 0.0) && (tn <= tf);
+            const int cnt = nd->tri_count;
+            if (!touch) {
+                i = nd->skip;
+                continue;
+            }
+            i = i + 1;  // inner: left child is next in preorder; leaf: its skip is i+1 too
+            if (cnt < 0) continue;
+            leaf_begin = nd->tri_begin;
+            leaf_cnt_tris = cnt;
+            break;
         }
-        i = i + 1;  // inner: left child is next in preorder; leaf: its skip is i+1 too
-        if (cnt < 0) continue;
+        if (leaf_cnt_tris < 0) break;  // no further leaf for this lane
         // leaf scan, objects.h:273-289
         double leaf_len = kInf;
         int leaf_tri = -1, leaf_cnt = 0;
-        const TriRec *tp = tris + nd->tri_begin;
-        for (int k = 0; k < cnt; k++) {
+        const TriRec *tp = tris + leaf_begin;
+        for (int k = 0; k < leaf_cnt_tris; k++) {
             if (STATS) n_tri++;
             const V3 pa = ld3(tp[k].pa), e1 = ld3(tp[k].e1), e2 = ld3(tp[k].e2);
             const V3 s = pa - o;
@@ -176,7 +186,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
                 const double len = det2 / det1;
                 if (len < leaf_len) {
                     leaf_len = len;
-                    leaf_tri = nd->tri_begin + k;
+                    leaf_tri = leaf_begin + k;
                     leaf_cnt++;
                 }
             }
@@ -392,9 +402,25 @@ struct RayKey {
     bool explicit_key;
 };
 
+// tree traversal entry; `on` = this lane really has a ray for this tree (all lanes of the wave call it).
+// A wave-synchronous variant (one shared node sequence, records fetched through the scalar cache) was measured
+// and dropped: with sub-pixel triangles the union of 64 rays' leaf sets approaches their sum.
+template <bool STATS>
+__device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, int tr, bool on, V3 o, V3 d, V3 inv,
+                                            uint32_t &n_node, uint32_t &n_tri) {
+    const TreeRec T = sc.trees[tr];
+    TreeHit none;
+    none.len = kInf;
+    none.tri = -1;
+    none.counter = 0;
+    if (!on) return none;
+    return tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d, inv, n_node, n_tri);
+}
+
 template <bool TREES, bool BEZ, bool STATS>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
-                                                    V3 o, V3 d, const RayKey &rk, uint32_t &n_node, uint32_t &n_tri) {
+                                                    V3 o, V3 d, const RayKey &rk, bool on,
+                                                    uint32_t &n_node, uint32_t &n_tri) {
     SceneHit best;
     best.t = kInf;  // `nearest = INF`, main.cpp:54
     best.id = -1;
@@ -429,47 +455,45 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             const V3 pn = ld3(ob.b);
             const V3 dd = ld3(ob.a) - o;
             double len = dot(dd, pn) / dot(d, pn);
-            if (len > 0) {
-                V3 nrm = pn;
-                if (TREES) {
-                    const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
-                    if (tr >= 0) {
-                        const TreeRec T = sc.trees[tr];
-                        TreeHit h = tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d,
-                                                          inv, n_node, n_tri);
-                        if (h.counter > 0 && h.len < len && h.len > 0) {
-                            len = h.len;
-                            nrm = tree_normal(sc.tris + T.tri_begin, h, d);
-                        }
+            const bool ph = len > 0;
+            V3 nrm = pn;
+            if (TREES) {
+                const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
+                const bool want = on && ph;  // the bump tree is only consulted when the plane is hit (objects.h:508-513)
+                if (tr >= 0 && __ballot(want) != 0ull) {
+                    const TreeHit h = tree_hit<STATS>(sc, tr, want, o, d, inv, n_node, n_tri);
+                    if (want && h.counter > 0 && h.len < len && h.len > 0) {
+                        len = h.len;
+                        nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
                     }
                 }
-                if (len < best.t) {
-                    best.t = len;
-                    best.id = i;
-                    best.n = nrm;
-                    nsrc = 1;
-                }
+            }
+            if (ph && len < best.t) {
+                best.t = len;
+                best.id = i;
+                best.n = nrm;
+                nsrc = 1;
             }
         } else if (TREES && kind == KIND_MESH) {
             // TriangleMesh::intersect, objects.h:405-455
             const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
-            const TreeRec T = sc.trees[tr];
-            TreeHit h = tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d, inv,
-                                              n_node, n_tri);
-            if (h.counter > 0 && h.len < best.t) {
-                V3 nrm = tree_normal(sc.tris + T.tri_begin, h, d);
-                if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436
-                best.t = h.len;
-                best.id = i;
-                best.n = nrm;
-                nsrc = 1;
+            if (__ballot(on) != 0ull) {
+                const TreeHit h = tree_hit<STATS>(sc, tr, on, o, d, inv, n_node, n_tri);
+                if (on && h.counter > 0 && h.len < best.t) {
+                    V3 nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
+                    if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436
+                    best.t = h.len;
+                    best.id = i;
+                    best.n = nrm;
+                    nsrc = 1;
+                }
             }
         } else if (BEZ && kind == KIND_BEZIER) {
             const BezierRec &bz = sc.beziers[__builtin_amdgcn_readfirstlane(ob.aux)];
             Stream rs(rk.explicit_key ? rk.k : purpose_key(rk.k, ((uint64_t)rk.path << 16) | (uint64_t)(i + 1)));
             double len = 0;
             V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
-            if (bezier_intersect(bz, ld3(ob.a), ob.b[0], o, d, rs, len, nrm)) {
+            if (on && bezier_intersect(bz, ld3(ob.a), ob.b[0], o, d, rs, len, nrm)) {
                 if (len < best.t) {
                     best.t = len;
                     best.id = i;
@@ -577,10 +601,12 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_gri
         }
         if (__ballot(have) == 0ull) break;  // every lane of the wave has drained its pixel
         wave_iters++;
+        // All 64 lanes enter the scene walk together (lanes without a ray carry on == false): the object list
+        // is wave-uniform, so its control flow stays scalar.
+        const RayKey rk{k_smp, path, false};
+        const SceneHit hit = intersect_scene<TREES, BEZ, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, my_nodes, my_tris);
         if (have) {
             my_rays++;
-            const RayKey rk{k_smp, path, false};
-            const SceneHit hit = intersect_scene<TREES, BEZ, STATS>(lobjs, sc.n_objs, sc, o, d, rk, my_nodes, my_tris);
             have = false;
             if (hit.id >= 0) {
                 const ObjRec &ob = lobjs[hit.id];
@@ -743,7 +769,7 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     const V3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
     DeviceScene one = sc;
     const RayKey rk{keys ? keys[i] : 0ull, 1, true};
-    SceneHit h = intersect_scene<true, true, false>(sc.objs + obj, 1, one, o, d, rk, a, b);
+    SceneHit h = intersect_scene<true, true, false>(sc.objs + obj, 1, one, o, d, rk, true, a, b);
     hit[i] = h.id >= 0 ? 1 : 0;
     len[i] = h.t;
     nrm[3 * i] = h.n.x;

@@ -49,6 +49,9 @@ if __name__ == "__main__":
     if "c4" in which:
         run("c4 dragon dof", scenes.scene_dragon(), scenes.cam_dof(), 2048, 2048, 4, 5, reps=2, stats=True)
         run("c4 dragon dof nostat", scenes.scene_dragon(), scenes.cam_dof(), 2048, 2048, 4, 5, reps=2)
+        run("c4 dragon 1024 spp16", scenes.scene_dragon(), scenes.cam_dof(), 1024, 1024, 16, 5, reps=2)
+        run("c4 dragon 512 spp64", scenes.scene_dragon(), scenes.cam_dof(), 512, 512, 64, 5, reps=2)
+        run("c4 dragon 2048 spp16", scenes.scene_dragon(), scenes.cam_dof(), 2048, 2048, 16, 5, reps=1)
     if "c5" in which:
         tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
         run("c5 bump only", scenes.planes(tex), scenes.cam_dof(), 1024, 1024, 2, 5, reps=1, stats=True)
