@@ -92,37 +92,59 @@ def main():
     n = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; CGRT_BENCH_BACKEND=gloo lets several ranks share a GPU to rehearse the N > 1 control path
+    backend = os.environ.get("CGRT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     Ht = H * n  # weak scaling: 1080 rows per GPU
-    scene = cg.Scene(scenes.scene_c2(), device=local_rank)
+    scene = cg.Scene(scenes.scene_c2(), device=dev_index)
     cam = scenes.cam_dof()
     stats = scene.stats()
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
 
     sr = StripedRenderer(W, Ht, stripe_rows=args.stripe_rows)
     rows_local = sr.rows_local
-    out = torch.zeros((rows_local, W, 3), dtype=torch.float32, device=dev)
+    # Two output buffers: with N > 1 the gather of frame k (side stream) overlaps the render of frame k+1.
+    outs = [torch.zeros((rows_local, W, 3), dtype=torch.float32, device=dev) for _ in range(2 if n > 1 else 1)]
     kernel_events = []
+    comm = torch.cuda.Stream(device=dev) if n > 1 else None
+    done_evt = [torch.cuda.Event() for _ in outs]
+    free_evt = [None for _ in outs]
+    state = {"k": 0}
 
-    def render_local(rows, stripe, record=False):
+    def step(record=False):
+        k = state["k"] % len(outs)
+        state["k"] += 1
+        out = outs[k]
+        cur = torch.cuda.current_stream(dev)
+        if free_evt[k] is not None:
+            cur.wait_event(free_evt[k])  # the gather that last read this buffer has finished
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        scene.trace_grid(W, Ht, SPP, cam, DEPTH, SEED, rows=rows, stripe=stripe, out=out, nhit=False,
+        scene.trace_grid(W, Ht, SPP, cam, DEPTH, SEED, rows=rows_local, stripe=sr.stripe, out=out, nhit=False,
                          counters=counters)
         if record:
             e1.record()
             kernel_events.append((e0, e1))
-        return out
-
-    def step(record=False):
-        local = render_local(rows_local, sr.stripe, record)
-        return sr.gather(local)
+        if n == 1:
+            return out[:Ht]
+        done_evt[k].record(cur)
+        with torch.cuda.stream(comm):
+            comm.wait_event(done_evt[k])
+            frame = sr.gather(out)  # RCCL gather to rank 0 + un-permute, on the side stream
+            ev = torch.cuda.Event()
+            ev.record(comm)
+            free_evt[k] = ev
+        return frame
 
     def fence():
         if n > 1:
@@ -140,8 +162,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    cnt = counters.clone()
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    cnt = counters.clone().to(red_dev)
     if n > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -173,7 +196,7 @@ def main():
                        "gather to rank 0" % args.stripe_rows if n > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                         "kernel": "trace_grid_kernel<false,true,false>", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "trace_grid_kernel<TREES=0,BEZ=0,DOF=1,GLASS=1,STATS=0>", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes": int(alg_bytes),
                          "note": "FP64-VALU/divergence bound by design (SURVEY.md §8d H5); HBM fraction reported as required",
                          "kernel_mrays_per_s": round(rays_per_step / n / (kern_ms * 1e-3) / 1e6, 2),

@@ -74,6 +74,8 @@ class StripedRenderer:
 
         if self.nranks == 1:
             return local[: self.H]
+        if local.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            local = local.cpu()  # rehearsal on machines without RCCL-capable peers: gloo gathers host tensors
         if self.rank == 0:
             if self._gather_buf is None or self._gather_buf.shape[1:] != local.shape or \
                     self._gather_buf.device != local.device:
