@@ -402,6 +402,24 @@ struct RayKey {
     bool explicit_key;
 };
 
+// Sphere::intersect, objects.h:45-68: the hit distance, or +inf-like kInf (never < nearest) on a miss
+__device__ __forceinline__ double sphere_len(const ObjRec &ob, V3 o, V3 d) {
+    const V3 l = ld3(ob.a) - o;
+    const double tca = dot(l, d);
+    const double l2 = dot(l, l);
+    const double r2 = ob.s0;
+    double len = kInf;
+    if (!(tca < 0 && l2 > r2)) {
+        const double d2 = l2 - tca * tca;
+        if (!(d2 > r2)) {
+            const double thc = sqrt(r2 - d2);
+            const double t0 = tca - thc, t1 = tca + thc;
+            len = (t0 < 0) ? t1 : t0;
+        }
+    }
+    return len;
+}
+
 // tree traversal entry; `on` = this lane really has a ray for this tree (all lanes of the wave call it).
 // A wave-synchronous variant (one shared node sequence, records fetched through the scalar cache) was measured
 // and dropped: with sub-pixel triangles the union of 64 rays' leaf sets approaches their sum.
@@ -417,7 +435,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, int tr, bool 
     return tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d, inv, n_node, n_tri);
 }
 
-template <bool TREES, bool BEZ, bool STATS>
+template <bool TREES, bool BEZ, bool SPH, bool STATS>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
                                                     V3 o, V3 d, const RayKey &rk, bool on,
                                                     uint32_t &n_node, uint32_t &n_tri) {
@@ -426,29 +444,29 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
     best.id = -1;
     best.n = mk(0, 0, 0);
     int nsrc = 0;  // 0: sphere (normal derived after the loop), 1: stored in best.n
+    if (SPH) {
+        // scenes made of spheres only: no kind dispatch, nothing but (t, id) carried round the loop
+        for (int i = 0; i < n_objs; i++) {
+            const double len = sphere_len(objs[i], o, d);
+            if (len < best.t) {
+                best.t = len;
+                best.id = i;
+            }
+        }
+        if (best.id >= 0) best.n = normalized((o + d * best.t) - ld3(objs[best.id].a));  // objects.h:65-66
+        return best;
+    }
     V3 inv = mk(0, 0, 0);
     if (TREES) inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     for (int i = 0; i < n_objs; i++) {
         const ObjRec &ob = objs[i];
         const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
         if (kind == KIND_SPHERE) {
-            // Sphere::intersect, objects.h:45-68
-            const V3 l = ld3(ob.a) - o;
-            const double tca = dot(l, d);
-            const double l2 = dot(l, l);
-            const double r2 = ob.s0;
-            if (!(tca < 0 && l2 > r2)) {
-                const double d2 = l2 - tca * tca;
-                if (!(d2 > r2)) {
-                    const double thc = sqrt(r2 - d2);
-                    const double t0 = tca - thc, t1 = tca + thc;
-                    const double len = (t0 < 0) ? t1 : t0;
-                    if (len < best.t) {
-                        best.t = len;
-                        best.id = i;
-                        nsrc = 0;
-                    }
-                }
+            const double len = sphere_len(ob, o, d);
+            if (len < best.t) {
+                best.t = len;
+                best.id = i;
+                nsrc = 0;
             }
         } else if (kind == KIND_PLANE) {
             // Plane::intersect, objects.h:505-524
@@ -521,7 +539,8 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
 
 // GLASS: the scene contains a transparent object, so refracted children can be pending; without it the
 // pending-ray storage (LDS levels, sibling registers) is compiled out and occupancy goes up.
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool STATS>
+// SPH: every object is a sphere (C1/C2-type scenes): specialised object loop.
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS>
 __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters) {
@@ -604,7 +623,8 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_gri
         // All 64 lanes enter the scene walk together (lanes without a ray carry on == false): the object list
         // is wave-uniform, so its control flow stays scalar.
         const RayKey rk{k_smp, path, false};
-        const SceneHit hit = intersect_scene<TREES, BEZ, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, my_nodes, my_tris);
+        const SceneHit hit =
+            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, my_nodes, my_tris);
         if (have) {
             my_rays++;
             have = false;
@@ -769,7 +789,7 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     const V3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
     DeviceScene one = sc;
     const RayKey rk{keys ? keys[i] : 0ull, 1, true};
-    SceneHit h = intersect_scene<true, true, false>(sc.objs + obj, 1, one, o, d, rk, true, a, b);
+    SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, one, o, d, rk, true, a, b);
     hit[i] = h.id >= 0 ? 1 : 0;
     len[i] = h.t;
     nrm[3 * i] = h.n.x;
@@ -1049,19 +1069,21 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
     const bool stats = (grid->flags & 1) != 0 && trees && !bez;
     if (!glass) lds -= kStackBytes;
-#define LAUNCH(T, B, D, G, S) \
-    hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
-#define LAUNCH_DG(T, B, S)                                         \
+#define LAUNCH(T, B, D, G, P, S) \
+    hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
+#define LAUNCH_DG(T, B, P, S)                                      \
     do {                                                           \
-        if (dof) { if (glass) LAUNCH(T, B, true, true, S); else LAUNCH(T, B, true, false, S); }   \
-        else     { if (glass) LAUNCH(T, B, false, true, S); else LAUNCH(T, B, false, false, S); } \
+        if (dof) { if (glass) LAUNCH(T, B, true, true, P, S); else LAUNCH(T, B, true, false, P, S); }   \
+        else     { if (glass) LAUNCH(T, B, false, true, P, S); else LAUNCH(T, B, false, false, P, S); } \
     } while (0)
     if (bez) {  // Bezier scenes share the tree-capable variants (the tree code is skipped when there is no tree)
-        LAUNCH_DG(true, true, false);
+        LAUNCH_DG(true, true, false, false);
     } else if (trees) {
-        if (stats) LAUNCH_DG(true, false, true); else LAUNCH_DG(true, false, false);
+        if (stats) LAUNCH_DG(true, false, false, true); else LAUNCH_DG(true, false, false, false);
+    } else if (s->dev.all_spheres) {
+        LAUNCH_DG(false, false, true, false);
     } else {
-        LAUNCH_DG(false, false, false);
+        LAUNCH_DG(false, false, false, false);
     }
 #undef LAUNCH_DG
 #undef LAUNCH
