@@ -601,8 +601,10 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_gri
                     Stream rs(k_smp);  // purpose 0: the lens stream's key is the sample key
                     double sx, sy;
                     while (true) {  // uniform_sampling_circle, sampling.h:35-43
-                        sx = rs.u01() * 2.0 - 1;
-                        sy = rs.u01() * 2.0 - 1;
+                        double ux, uy;
+                        rs.pair(ux, uy);
+                        sx = ux * 2.0 - 1;
+                        sy = uy * 2.0 - 1;
                         if (sx * sx + sy * sy < 1) break;
                     }
                     o = camorg + mk(sx, sy, 0) * g.lens_radius;
@@ -1162,8 +1164,10 @@ int cgrt_lens_samples(uint64_t seed, const int64_t *pixel, const int32_t *sample
         Stream rs(stream_key(seed, (uint64_t)pixel[i], (uint64_t)sample[i], 0));
         double sx, sy;
         while (true) {
-            sx = rs.u01() * 2.0 - 1;
-            sy = rs.u01() * 2.0 - 1;
+            double ux, uy;
+            rs.pair(ux, uy);
+            sx = ux * 2.0 - 1;
+            sy = uy * 2.0 - 1;
             if (sx * sx + sy * sy < 1) break;
         }
         out3[3 * i] = sx * radius;

@@ -7,7 +7,8 @@
 //   k_pix = fin(fin(seed+G) + pixel + G)          once per pixel        G = 0x9E3779B97F4A7C15 (splitmix64)
 //   k_smp = fin(k_pix + sample + G)               once per sample; this IS the lens stream's key (purpose 0)
 //   key   = fin(k_smp + purpose + G)              other purposes (>= 1)
-//   r31   = fin(key + (i+1)*G) >> 33              31 random bits, like glibc rand(); i.e. splitmix64 seeded with key
+//   z_j   = fin(key + (j+1)*G)                    splitmix64 seeded with key; each 64-bit z_j gives TWO draws:
+//   r31[2j] = z_j >> 33,  r31[2j+1] = (z_j >> 2) & 0x7fffffff       31 random bits each, like glibc rand()
 //   u01   = (double)r31 / 2147483647.0            same value as sampling.h:32's rand()/RAND_MAX
 //
 // The division by RAND_MAX is evaluated as q0 = r*rc, q = fma(fma(-q0, D, r), rc, q0) with rc = fl(1/D): verified
@@ -58,11 +59,27 @@ CGRT_HD double div_rand_max(uint32_t r) {
 }
 
 struct Stream {
-    uint64_t state;  // key + i*G
-    CGRT_HD explicit Stream(uint64_t key) : state(key) {}
+    uint64_t state;   // key + j*G
+    uint32_t spare;   // second draw of the current z_j
+    bool has_spare;
+    CGRT_HD explicit Stream(uint64_t key) : state(key), spare(0), has_spare(false) {}
     CGRT_HD uint32_t next31() {
+        if (has_spare) {
+            has_spare = false;
+            return spare;
+        }
         state += kGolden;
-        return (uint32_t)(fin64(state) >> 33);
+        const uint64_t z = fin64(state);
+        spare = (uint32_t)((z >> 2) & 0x7fffffffu);
+        has_spare = true;
+        return (uint32_t)(z >> 33);
+    }
+    // two consecutive draws at an even position of the stream (the lens sampler's x, y): one finaliser
+    CGRT_HD void pair(double &a, double &b) {
+        state += kGolden;
+        const uint64_t z = fin64(state);
+        a = div_rand_max((uint32_t)(z >> 33));
+        b = div_rand_max((uint32_t)((z >> 2) & 0x7fffffffu));
     }
     CGRT_HD double u01() { return div_rand_max(next31()); }
 };

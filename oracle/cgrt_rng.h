@@ -7,8 +7,9 @@
  * of this integer recipe in cgraytracing_amd/csrc/cgrt_rng.hpp; tests check
  * the two agree bit for bit.
  *
- * stream(K)[i] = splitmix64 finaliser of (K + (i+1)*GOLDEN) >> 33   (31 bits; i.e. splitmix64 seeded with K)
- * u01          = (double)r31 / 2147483647.0      (RAND_MAX of glibc)
+ * splitmix64 seeded with K: z_j = fin(K + (j+1)*GOLDEN), j = 0,1,...  Each 64-bit output yields TWO 31-bit
+ * draws: stream(K)[2j] = z_j >> 33, stream(K)[2j+1] = (z_j >> 2) & 0x7fffffff.
+ * u01 = (double)r31 / 2147483647.0      (RAND_MAX of glibc)
  */
 #ifndef CGRT_ORACLE_RNG_H
 #define CGRT_ORACLE_RNG_H
@@ -34,6 +35,7 @@ static inline uint64_t cgrt_key(uint64_t seed, uint64_t a, uint64_t b, uint64_t 
     return k;
 }
 static inline uint32_t cgrt_rand31(uint64_t key, uint32_t i) {
-    return (uint32_t)(cgrt_fin64(key + (uint64_t)(i + 1u) * CGRT_GOLDEN) >> 33);
+    uint64_t z = cgrt_fin64(key + (uint64_t)(i / 2u + 1u) * CGRT_GOLDEN);
+    return (i & 1u) ? (uint32_t)((z >> 2) & 0x7fffffffu) : (uint32_t)(z >> 33);
 }
 #endif
