@@ -78,13 +78,15 @@ static constexpr int kMaxObjs = 96;  // top-level objects staged in LDS (12 KiB)
 //   * a glass hit whose children are leaves of the recursion (depth_left == 2) keeps the refracted child in
 //     REGISTERS (it is consumed right after the reflected child, before any other push) -- in a full glass tree
 //     that is 8 of the 15 pushes;
-//   * the first two other levels live in LDS (2 x 10 doubles x 256 threads = 40 KiB per workgroup, layout
-//     [level][field][thread]: conflict-free 8-byte accesses);
+//   * the first two other levels live in LDS: per level 9 doubles + one packed (depth, path) word per thread,
+//     layout [level][field][thread] (conflict-free), 2 x 19 456 B = 38 912 B per workgroup;
 //   * a third level (three nested glass hits with all siblings waiting) spills to scratch memory.
-// 40 KiB + objs + tile keeps 3 workgroups = 3 waves/SIMD per CU, measured to be as fast as 4.
-static constexpr int kPendDoubles = 10;
+// The output tile aliases the stack (dead by then), so stack + objs stays under 40 KiB and FOUR workgroups fit a
+// CU's 160 KiB: occupancy 4 waves/SIMD instead of 3, worth ~10 % on C2.
+static constexpr int kPendDoubles = 9;
 static constexpr int kLdsLevels = 2;
-static constexpr size_t kStackBytes = (size_t)kLdsLevels * kPendDoubles * kThreads * sizeof(double);
+static constexpr size_t kLevelBytes = (size_t)kThreads * (kPendDoubles * sizeof(double) + sizeof(uint32_t));
+static constexpr size_t kStackBytes = (size_t)kLdsLevels * kLevelBytes;
 static constexpr size_t kTileBytes = (size_t)8 * 32 * 3 * sizeof(float);
 
 // local row -> global row (cgrt.h: block-cyclic stripes)
@@ -541,14 +543,13 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
 // pending-ray storage (LDS levels, sibling registers) is compiled out and occupancy goes up.
 // SPH: every object is a sphere (C1/C2-type scenes): specialised object loop.
 template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS>
-__global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+__global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters) {
-    // LDS carve-up: [ pending-ray slot 0: kPendDoubles x 256 doubles | objs | output tile ]
+    // LDS carve-up: [ pending-ray levels (GLASS) -- aliased by the output tile at the end | objs ]
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    double *lstack = reinterpret_cast<double *>(lds_raw);  // [field][thread], conflict-free 8-byte accesses
-    float *ltile = reinterpret_cast<float *>(lds_raw + (GLASS ? kStackBytes : 0));
-    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? kStackBytes : 0) + kTileBytes);  // n_objs records
+    float *ltile = reinterpret_cast<float *>(lds_raw);
+    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? kStackBytes : kTileBytes));  // n_objs records
 
     // stage the primitive list in LDS (128 B records, copied as 16-byte pieces)
     {
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_gri
     Pending deep[2];   // third stack level (scratch; indexed dynamically so that it stays out of registers)
     Pending sib;       // refracted sibling of a leaf-level glass hit (registers)
     bool sib_valid = false;
-    double *lslot = lstack + threadIdx.x;
+    unsigned char *lslot = lds_raw;  // level L, field f of this thread: lslot + L*kLevelBytes + (f*256 + tid)*8
     int sp = 0;
     int s = 0;  // next sample to start
     bool have = false;
@@ -692,11 +693,14 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_gri
                                 sib_valid = true;
                             } else {
                                 if (sp < kLdsLevels) {
-                                    double *q = lslot + sp * (kPendDoubles * kThreads);
+                                    double *q = reinterpret_cast<double *>(lslot + sp * kLevelBytes) + threadIdx.x;
                                     q[0 * kThreads] = pe.o.x; q[1 * kThreads] = pe.o.y; q[2 * kThreads] = pe.o.z;
                                     q[3 * kThreads] = pe.d.x; q[4 * kThreads] = pe.d.y; q[5 * kThreads] = pe.d.z;
                                     q[6 * kThreads] = pe.adj.x; q[7 * kThreads] = pe.adj.y; q[8 * kThreads] = pe.adj.z;
-                                    q[9 * kThreads] = __hiloint2double(pe.depth_left, (int)pe.path);
+                                    // depth_left <= 4 and path < 32: one word
+                                    reinterpret_cast<uint32_t *>(lslot + sp * kLevelBytes +
+                                                                 kPendDoubles * kThreads * sizeof(double))[threadIdx.x] =
+                                        ((uint32_t)pe.depth_left << 8) | pe.path;
                                 } else {
                                     deep[sp - kLdsLevels] = pe;
                                 }
@@ -724,13 +728,14 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_gri
             if (GLASS && !have && sp > 0) {
                 --sp;
                 if (sp < kLdsLevels) {
-                    const double *q = lslot + sp * (kPendDoubles * kThreads);
+                    const double *q = reinterpret_cast<const double *>(lslot + sp * kLevelBytes) + threadIdx.x;
                     o = mk(q[0 * kThreads], q[1 * kThreads], q[2 * kThreads]);
                     d = mk(q[3 * kThreads], q[4 * kThreads], q[5 * kThreads]);
                     adj = mk(q[6 * kThreads], q[7 * kThreads], q[8 * kThreads]);
-                    const double meta = q[9 * kThreads];
-                    depth_left = __double2hiint(meta);
-                    path = (uint32_t)__double2loint(meta);
+                    const uint32_t meta = reinterpret_cast<const uint32_t *>(
+                        lslot + sp * kLevelBytes + kPendDoubles * kThreads * sizeof(double))[threadIdx.x];
+                    depth_left = (int)(meta >> 8);
+                    path = meta & 0xffu;
                 } else {
                     const Pending &pe = deep[sp - kLdsLevels];
                     o = pe.o;
@@ -745,6 +750,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : (GLASS ? 3 : 4)) void trace_gri
     }
 
     // ---- coalesced store through LDS: 32 px x 3 floats = 384 contiguous bytes per tile row ----
+    if (GLASS) __syncthreads();  // every wave is done with the pending-ray levels the tile aliases
     ltile[ly * (kTileW * 3) + lx * 3 + 0] = (float)(acc_r * g.inv_spp_total);
     ltile[ly * (kTileW * 3) + lx * 3 + 1] = (float)(acc_g * g.inv_spp_total);
     ltile[ly * (kTileW * 3) + lx * 3 + 2] = (float)(acc_b * g.inv_spp_total);
@@ -1063,14 +1069,14 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
 
     const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
     const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
-    size_t lds = kStackBytes + kTileBytes + (size_t)s->dev.n_objs * sizeof(ObjRec);
+    size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
     if (const char *e = getenv("CGRT_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiments only
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
     const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0, bez = s->dev.has_bezier != 0;
     const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
     const bool stats = (grid->flags & 1) != 0 && trees && !bez;
-    if (!glass) lds -= kStackBytes;
+    lds += glass ? kStackBytes : kTileBytes;
 #define LAUNCH(T, B, D, G, P, S) \
     hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
 #define LAUNCH_DG(T, B, P, S)                                      \

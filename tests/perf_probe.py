@@ -43,6 +43,18 @@ if __name__ == "__main__":
         run("c2 dof d1", scenes.scene_c2(), scenes.cam_dof(), 1920, 1080, 64, 1)
         run("c2 pinhole d1", scenes.scene_c2(), scenes.cam_pinhole(), 1920, 1080, 64, 1)
         run("c1 pinhole d1", scenes.scene_c1(), scenes.cam_pinhole(), 1920, 1080, 64, 1)
+        m = scenes.wall_spheres() + [scenes.Sphere((-15.0, -20.0, 60), 10, (0.3, 0.3, 0.3), 0.0, 0.0),
+                                     scenes.Sphere((10.0, -13.0, 30), 7, (1.0, 1.0, 1.0), 0.8, 0.0),
+                                     scenes.Sphere((-8.0, -13.0, 25), 7, (1.0, 1.0, 1.0), 0.8, 0.0)]
+        run("c2 two mirrors pinhole d5", m, scenes.cam_pinhole(), 1920, 1080, 64, 5)
+        g = scenes.wall_spheres() + [scenes.Sphere((-15.0, -20.0, 60), 10, (0.3, 0.3, 0.3), 0.0, 0.0),
+                                     scenes.Sphere((10.0, -13.0, 30), 7, (1.0, 1.0, 1.0), 0.0, 0.0),
+                                     scenes.Sphere((-8.0, -13.0, 25), 7, (1.0, 1.0, 1.0), 0.8, 0.5)]
+        run("c2 glass only pinhole d5", g, scenes.cam_pinhole(), 1920, 1080, 64, 5)
+        g2 = scenes.wall_spheres() + [scenes.Sphere((-15.0, -20.0, 60), 10, (0.3, 0.3, 0.3), 0.0, 0.0),
+                                      scenes.Sphere((10.0, -13.0, 30), 7, (1.0, 1.0, 1.0), 0.0, 0.0),
+                                      scenes.Sphere((-8.0, -13.0, 25), 0.01, (1.0, 1.0, 1.0), 0.8, 0.5)]
+        run("c2 tiny glass pinhole d5", g2, scenes.cam_pinhole(), 1920, 1080, 64, 5)
     if "c3" in which:
         run("c3 bunny glass dof", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 16, 5, reps=2, stats=True)
         run("c3 bunny glass dof nostat", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 16, 5, reps=2)
