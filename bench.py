@@ -196,7 +196,7 @@ def main():
                        "gather to rank 0" % args.stripe_rows if n > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                         "kernel": "trace_grid_kernel<TREES=0,BEZ=0,DOF=1,GLASS=1,STATS=0>", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "trace_grid_kernel<TREES=0,BEZ=0,DOF=1,GLASS=1,SPH=1,STATS=0>", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes": int(alg_bytes),
                          "note": "FP64-VALU/divergence bound by design (SURVEY.md §8d H5); HBM fraction reported as required",
                          "kernel_mrays_per_s": round(rays_per_step / n / (kern_ms * 1e-3) / 1e6, 2),
