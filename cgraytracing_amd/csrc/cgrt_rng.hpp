@@ -12,7 +12,7 @@
 //   u01   = (double)r31 / 2147483647.0            same value as sampling.h:32's rand()/RAND_MAX
 //
 // The division by RAND_MAX is evaluated as q0 = r*rc, q = fma(fma(-q0, D, r), rc, q0) with rc = fl(1/D): verified
-// exhaustively (all 2^31 inputs, tests/test_rng_division.py runs a sample; DESIGN.md has the full-sweep program) to
+// exhaustively (all 2^31 inputs: tests/test_rng_division.py) to
 // equal the correctly rounded quotient, at 3 instructions instead of the ~15 of an IEEE divide.
 //
 // pixel = h*W + w on the GLOBAL image, so a render is independent of how rows are sharded over GPUs.
