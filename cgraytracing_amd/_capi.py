@@ -64,6 +64,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p]),
     "cgrt_trace_grid_host": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "cgrt_trace_grid_hitpoints": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_uint64,
+                                            C.POINTER(C.c_uint64)]),
     "cgrt_lens_samples": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "cgrt_intersect_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -542,10 +542,18 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
 // GLASS: the scene contains a transparent object, so refracted children can be pending; without it the
 // pending-ray storage (LDS levels, sibling registers) is compiled out and occupancy goes up.
 // SPH: every object is a sphere (C1/C2-type scenes): specialised object loop.
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS>
+// HPS: additionally append every Hitpoint {f, pos, normal} (hitpoints.h:6-20, main.cpp:87-98) to a global stream.
+struct HitpointSink {
+    double *rec;                // cap x 10 doubles: f(3) pos(3) normal(3) label
+    unsigned long long *count;  // appended so far (may exceed cap: then the tail was dropped)
+    unsigned long long cap;
+};
+
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false>
 __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
-                                                             unsigned long long *__restrict__ counters) {
+                                                             unsigned long long *__restrict__ counters,
+                                                             HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
     // LDS carve-up: [ pending-ray levels (GLASS) -- aliased by the output tile at the end | objs ]
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float *ltile = reinterpret_cast<float *>(lds_raw);
@@ -654,6 +662,18 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
                     acc_g += hf.y;
                     acc_b += hf.z;
                     my_hits++;
+                    if (HPS) {
+                        const unsigned long long k = atomicAdd(hps.count, 1ull);
+                        if (k < hps.cap) {
+                            double *q = hps.rec + 10 * k;
+                            q[0] = hf.x; q[1] = hf.y; q[2] = hf.z;
+                            q[3] = P.x; q[4] = P.y; q[5] = P.z;
+                            q[6] = n.x; q[7] = n.y; q[8] = n.z;
+                            // label: local pixel index and sample index, like Hitpoint::w/h (main.cpp:91-92)
+                            q[9] = (double)((unsigned long long)(s - 1) * (unsigned long long)g.W * g.rows +
+                                            (unsigned long long)j * g.W + w);
+                        }
+                    }
                 } else if (depth_left > 1) {
                     if (transp < kEps) {
                         // mirror, main.cpp:129-134
@@ -1097,6 +1117,53 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return CGRT_OK;
+}
+
+int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, double *hp10,
+                              uint64_t cap, uint64_t *count) {
+    int rc = check_grid(s, cam, grid);
+    if (rc) return rc;
+    if (!count || (cap > 0 && !hp10)) return fail(CGRT_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(s->device));
+    GridParams g;
+    g.W = grid->width; g.H = grid->height; g.rows = grid->rows; g.row_offset = grid->row_offset;
+    g.stripe_rows = grid->stripe_rows; g.stripe_rank = grid->stripe_rank; g.stripe_nranks = grid->stripe_nranks;
+    g.spp = grid->spp; g.sample_offset = grid->sample_offset; g.max_depth = grid->max_depth;
+    g.inv_spp_total = 1.0 / (double)grid->spp_total;
+    g.seed = grid->seed;
+    for (int k = 0; k < 3; k++) g.cam[k] = cam->cam[k];
+    g.half_width = cam->half_width; g.focus_plane = cam->focus_plane; g.lens_radius = cam->lens_radius;
+    const size_t npx = (size_t)grid->rows * grid->width;
+    float *d_rgb = nullptr;
+    double *d_rec = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rgb, npx * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_rec, (cap ? cap : 1) * 10 * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
+    const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
+    const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
+    const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec) + kStackBytes;
+    HitpointSink sink{d_rec, d_cnt, (unsigned long long)cap};
+    // the most general variant serves every scene; capture is a verification / hand-off path, not the hot path
+    if (cam->lens_radius > 0)
+        hipLaunchKernelGGL((trace_grid_kernel<true, true, true, true, false, false, true>), grid_dim, block, lds, 0,
+                           s->dev, g, d_rgb, (uint32_t *)nullptr, (unsigned long long *)nullptr, sink);
+    else
+        hipLaunchKernelGGL((trace_grid_kernel<true, true, false, true, false, false, true>), grid_dim, block, lds, 0,
+                           s->dev, g, d_rgb, (uint32_t *)nullptr, (unsigned long long *)nullptr, sink);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = fail(CGRT_ERR_DEVICE, std::string("hitpoint kernel: ") + hipGetErrorString(e));
+    unsigned long long n = 0;
+    if (rc == CGRT_OK) {
+        HIP_TRY(hipMemcpy(&n, d_cnt, sizeof(n), hipMemcpyDeviceToHost));
+        *count = n;
+        const unsigned long long m = n < cap ? n : cap;
+        if (m) HIP_TRY(hipMemcpy(hp10, d_rec, (size_t)m * 10 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_rgb); (void)hipFree(d_rec); (void)hipFree(d_cnt);
+    return rc;
 }
 
 int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,

@@ -146,6 +146,20 @@ class Scene:
         return dict(rgb=rgb, nhit=nhit, counters=cnt, nrays=int(cnt[_capi.CNT_RAYS]),
                     nhp=int(cnt[_capi.CNT_HITPOINTS]))
 
+    def trace_grid_hitpoints(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, rows=None,
+                             row_offset=0, cap=None):
+        """The reference's Hitpoint records for the grid (unordered): dict(hp [n,9] = f,pos,normal; pix [n];
+        smp [n]; count)."""
+        rows = height - row_offset if rows is None else rows
+        cap = int(cap if cap is not None else rows * width * spp * 16)
+        rec = np.zeros((max(cap, 1), 10), np.float64)
+        n = C.c_uint64(0)
+        cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, None, 0, None, 0)
+        check(self._L.cgrt_trace_grid_hitpoints(self._h, C.byref(cc), C.byref(g), rec.ctypes.data, cap, C.byref(n)))
+        m = min(int(n.value), cap)
+        lab = rec[:m, 9].astype(np.int64)
+        return dict(hp=rec[:m, :9].copy(), pix=lab % (rows * width), smp=lab // (rows * width), count=int(n.value))
+
     def intersect_rays(self, obj, org, dirs, keys=None):
         org = np.ascontiguousarray(org, np.float64)
         dirs = np.ascontiguousarray(dirs, np.float64)

@@ -150,6 +150,14 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
 int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,
                          uint32_t *nhit, uint64_t *counters);
 
+/* The Hitpoint stream the reference would have inserted into its hash table (main.cpp:87-98, hash.h:43-54), for
+ * the same grid: up to `cap` records of 10 doubles {f(3) = surface colour * adj, pos(3), normal(3), label} are written
+ * to the HOST buffer hp10 in no particular order; label = sample_index * (rows*width) + local pixel index.  *count
+ * receives the number of hitpoints produced (if > cap the excess was dropped).  This is the hand-off a photon pass
+ * would consume and what parity tests compare with the reference's own records. */
+int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, double *hp10,
+                              uint64_t cap, uint64_t *count);
+
 /* Function-level probe used by parity tests: objs[obj]->intersect(org, dir, len, normal) for n rays on the
  * device (host pointers; keys: per-ray stream key for Bezier draws, may be NULL). */
 int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const double *dir3, const uint64_t *keys,
