@@ -13,6 +13,15 @@ namespace {
 
 inline double hi3(double a, double b, double c) { return (a > b && a > c) ? a : (b > c ? b : c); }  // util.h:16-27
 inline double lo3(double a, double b, double c) { return (a < b && a < c) ? a : (b < c ? b : c); }  // util.h:33-42
+// nearest floats not above / not below v (outward rounding of the padded box)
+inline float round_down(double v) {
+    float f = (float)v;
+    return ((double)f > v) ? std::nextafterf(f, -INFINITY) : f;
+}
+inline float round_up(double v) {
+    float f = (float)v;
+    return ((double)f < v) ? std::nextafterf(f, INFINITY) : f;
+}
 
 // ---- tree build -------------------------------------------------------------------------------
 // The reference builds an object-median tree (it calls it a KD-tree): every node takes the triangle
@@ -49,13 +58,11 @@ struct Builder {
         }
         NodeRec nr;
         for (int k = 0; k < 3; k++) {
-            nr.lo[k] = mn[k] - kBoxPad;
-            nr.hi[k] = mx[k] + kBoxPad;
+            nr.lo[k] = round_down(mn[k] - kBoxPad);
+            nr.hi[k] = round_up(mx[k] + kBoxPad);
         }
         nr.skip = 0;
-        nr.tri_begin = 0;
-        nr.tri_count = -1;
-        nr.pad = 0;
+        nr.leaf = -1;
         out.nodes.push_back(nr);
         out.node_lr_size.push_back(-1);
         out.node_lr_size.push_back(-1);
@@ -65,8 +72,7 @@ struct Builder {
             out.bbox.push_back(mx[k]);
         }
         if ((int)n < kMinKd) {  // leaf (objects.h:251, 273)
-            out.nodes[me].tri_begin = (int32_t)out.tris.size();
-            out.nodes[me].tri_count = (int32_t)n;
+            out.nodes[me].leaf = (int32_t)(((uint32_t)out.tris.size() << 4) | (uint32_t)n);
             for (size_t i = b; i < e; i++) {
                 const double *t = &T[9 * (size_t)ids[i]];
                 TriRec tr;

@@ -140,31 +140,33 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
     while (true) {
         int leaf_begin = 0, leaf_cnt_tris = -1;
         while (i < nnodes) {
-            const NodeRec *nd = nodes + i;
+            // one 32-byte record = two 16-byte loads
+            const float4 q0 = reinterpret_cast<const float4 *>(nodes + i)[0];  // lo.x lo.y lo.z hi.x
+            const float4 q1 = reinterpret_cast<const float4 *>(nodes + i)[1];  // hi.y hi.z skip leaf
             if (STATS) n_node++;
             double t1, t2, tn, tf;
-            t1 = (nd->lo[0] - o.x) * inv.x;
-            t2 = (nd->hi[0] - o.x) * inv.x;
+            t1 = ((double)q0.x - o.x) * inv.x;
+            t2 = ((double)q0.w - o.x) * inv.x;
             tn = fmin(t1, t2);
             tf = fmax(t1, t2);
-            t1 = (nd->lo[1] - o.y) * inv.y;
-            t2 = (nd->hi[1] - o.y) * inv.y;
+            t1 = ((double)q0.y - o.y) * inv.y;
+            t2 = ((double)q1.x - o.y) * inv.y;
             tn = fmax(tn, fmin(t1, t2));
             tf = fmin(tf, fmax(t1, t2));
-            t1 = (nd->lo[2] - o.z) * inv.z;
-            t2 = (nd->hi[2] - o.z) * inv.z;
+            t1 = ((double)q0.z - o.z) * inv.z;
+            t2 = ((double)q1.y - o.z) * inv.z;
             tn = fmax(tn, fmin(t1, t2));
             tf = fmin(tf, fmax(t1, t2));
             const bool touch = (tf > 0.0) && (tn <= tf);
-            const int cnt = nd->tri_count;
+            const int leaf = __float_as_int(q1.w);
             if (!touch) {
-                i = nd->skip;
+                i = __float_as_int(q1.z);
                 continue;
             }
             i = i + 1;  // inner: left child is next in preorder; leaf: its skip is i+1 too
-            if (cnt < 0) continue;
-            leaf_begin = nd->tri_begin;
-            leaf_cnt_tris = cnt;
+            if (leaf < 0) continue;
+            leaf_begin = leaf >> 4;
+            leaf_cnt_tris = leaf & 15;
             break;
         }
         if (leaf_cnt_tris < 0) break;  // no further leaf for this lane

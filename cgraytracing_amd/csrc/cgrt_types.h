@@ -35,17 +35,18 @@ struct ObjRec {
 };
 static_assert(sizeof(ObjRec) == 128, "ObjRec layout");
 
-// Tree node in the reference's preorder numbering (objects.h:217-226), with a skip link instead of
-// child indices: next node when the subtree is abandoned.  Box already padded by kBoxPad.  64 B.
+// Tree node in the reference's preorder numbering (objects.h:217-226), with a skip link instead of child
+// indices: next node when the subtree is abandoned.  32 B = two 16-byte loads per lane (tree traversal is bound by
+// the number of vector-memory requests, not by arithmetic).  The box is the reference's box grown by kBoxPad and
+// then rounded OUTWARD to fp32: the box test only has to accept a superset of what KDNode::intersect accepts
+// (DESIGN.md section 4.2), so a slightly larger box is still exact for (len, triangle, counter).
 struct NodeRec {
-    double lo[3];
-    double hi[3];
-    int32_t skip;       // index of the first node after this subtree
-    int32_t tri_begin;  // leaves: first triangle in TriRec order
-    int32_t tri_count;  // leaves: 0..9 ; inner nodes: -1
-    int32_t pad;
+    float lo[3];
+    float hi[3];
+    int32_t skip;  // index of the first node after this subtree
+    int32_t leaf;  // inner node: -1; leaf: (first triangle in TriRec order << 4) | triangle count (0..9)
 };
-static_assert(sizeof(NodeRec) == 64, "NodeRec layout");
+static_assert(sizeof(NodeRec) == 32, "NodeRec layout");
 
 // Leaf triangle, stored in leaf order: pa and the two edge vectors the reference recomputes per test
 // (e1 = pa-pb, e2 = pa-pc, objects.h:98-99; same doubles).  72 B.

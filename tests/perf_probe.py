@@ -67,5 +67,5 @@ if __name__ == "__main__":
     if "c5" in which:
         tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
         run("c5 bump only", scenes.planes(tex), scenes.cam_dof(), 1024, 1024, 2, 5, reps=1, stats=True)
-        run("c5 bump+vase", scenes.scene_c5(tex), scenes.cam_dof(), 512, 512, 1, 5, reps=1)
-        run("vase only", scenes.planes() + [scenes.vase_bezier()], scenes.cam_dof(), 512, 512, 1, 5, reps=1)
+        run("c5 bump+vase", scenes.scene_c5(tex), scenes.cam_dof(), 1536, 1536, 2, 5, reps=1)
+        run("vase only", scenes.planes() + [scenes.vase_bezier()], scenes.cam_dof(), 1536, 1536, 2, 5, reps=1)
