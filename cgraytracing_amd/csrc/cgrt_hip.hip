@@ -67,6 +67,7 @@ __device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2])
 struct GridParams {
     int32_t W, H, rows, row_offset, stripe_rows, stripe_rank, stripe_nranks;
     int32_t spp, sample_offset, max_depth;
+    int32_t accumulate;  // CGRT_GRID_ACCUMULATE: rgb += this pass (nhit is overwritten)
     double inv_spp_total;
     uint64_t seed;
     double cam[3], half_width, focus_plane, lens_radius;
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
     const int tiles_x = (g.W + kTileW - 1) / kTileW;
     const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave = 16x4 pixels, 2x2 waves per workgroup (8x8 per wave measured: meshes equal, C2 7 % slower)
     const int lx = (wave & 1) * 16 + (lane & 15);
     const int ly = (wave >> 1) * 4 + (lane >> 4);
     const int w = tile_x * kTileW + lx;
@@ -781,7 +783,10 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
         const int row = k / (kTileW * 3), col = k % (kTileW * 3);
         const int jj = tile_y * kTileH + row;
         const int ww = tile_x * kTileW + col / 3;
-        if (jj < g.rows && ww < g.W) rgb[((size_t)jj * g.W + tile_x * kTileW) * 3 + col] = ltile[k];
+        if (jj < g.rows && ww < g.W) {
+            float *dst = rgb + ((size_t)jj * g.W + tile_x * kTileW) * 3 + col;
+            *dst = g.accumulate ? *dst + ltile[k] : ltile[k];  // progressive passes add into the fp32 frame
+        }
     }
     if (nhit_out && (w < g.W) && (j < g.rows)) nhit_out[(size_t)j * g.W + w] = my_hits;
 
@@ -1082,6 +1087,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.spp = grid->spp;
     g.sample_offset = grid->sample_offset;
     g.max_depth = grid->max_depth;
+    g.accumulate = (grid->flags & CGRT_GRID_ACCUMULATE) ? 1 : 0;
     g.inv_spp_total = 1.0 / (double)grid->spp_total;
     g.seed = grid->seed;
     for (int k = 0; k < 3; k++) g.cam[k] = cam->cam[k];
@@ -1092,12 +1098,11 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
     const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
     size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
-    if (const char *e = getenv("CGRT_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiments only
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
     const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0, bez = s->dev.has_bezier != 0;
     const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
-    const bool stats = (grid->flags & 1) != 0 && trees && !bez;
+    const bool stats = (grid->flags & CGRT_GRID_STATS) != 0 && trees && !bez;
     lds += glass ? kStackBytes : kTileBytes;
 #define LAUNCH(T, B, D, G, P, S) \
     hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
@@ -1131,6 +1136,7 @@ int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const
     g.W = grid->width; g.H = grid->height; g.rows = grid->rows; g.row_offset = grid->row_offset;
     g.stripe_rows = grid->stripe_rows; g.stripe_rank = grid->stripe_rank; g.stripe_nranks = grid->stripe_nranks;
     g.spp = grid->spp; g.sample_offset = grid->sample_offset; g.max_depth = grid->max_depth;
+    g.accumulate = 0;
     g.inv_spp_total = 1.0 / (double)grid->spp_total;
     g.seed = grid->seed;
     for (int k = 0; k < 3; k++) g.cam[k] = cam->cam[k];

@@ -107,7 +107,7 @@ class Scene:
 
     def trace_grid(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, rows=None, row_offset=0,
                    stripe=None, sample_offset=0, spp_total=None, out=None, nhit=None, counters=None, stream=None,
-                   stats=False):
+                   stats=False, accumulate=False):
         """Asynchronous launch on torch's current stream (or `stream`).  Returns (rgb, nhit, counters) torch
         tensors on the scene's device: float32 [rows,width,3], int32 [rows,width] (bit pattern uint32),
         int64 [8] (counters are ADDED to)."""
@@ -125,7 +125,7 @@ class Scene:
             counters = torch.zeros((_capi.CGRT_NCOUNTERS,), dtype=torch.int64, device=dev)
         assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (rows, width, 3)
         cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
-                              spp_total, 1 if stats else 0)
+                              spp_total, (1 if stats else 0) | (2 if accumulate else 0))
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         check(self._L.cgrt_trace_grid(self._h, C.byref(cc), C.byref(g), out.data_ptr(),
                                       nhit.data_ptr() if nhit is not None else None,

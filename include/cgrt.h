@@ -62,9 +62,16 @@ typedef struct cgrt_grid {
     int32_t sample_offset;  /* index of the first sample (keys the lens stream)                          */
     int32_t spp_total;      /* normaliser: output = sum / spp_total (== spp for a single pass)           */
     int32_t max_depth;      /* MAX_DEPTH, main.cpp:35 (1..5)                                             */
-    int32_t flags;          /* 0                                                                         */
+    int32_t flags;          /* bit set of CGRT_GRID_* below                                              */
     uint64_t seed;          /* seed of the counter-based lens / Bezier streams                           */
 } cgrt_grid;
+
+enum {
+    CGRT_GRID_STATS = 1,      /* also count tree-node and triangle tests (CGRT_CNT_NODE_TESTS / _TRI_TESTS)          */
+    CGRT_GRID_ACCUMULATE = 2  /* rgb += this pass instead of rgb = this pass: progressive multi-pass rendering with
+                                 sample_offset / spp_total, the fp32 replacement for the reference's average.cpp,
+                                 which averages nine uint8 images with truncating division (average.cpp:21-64)     */
+};
 
 /* indices into the uint64 counters[CGRT_NCOUNTERS] array written by cgrt_trace_grid (added to, not reset) */
 enum {

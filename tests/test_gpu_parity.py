@@ -196,3 +196,24 @@ def test_hitpoint_stream_matches_reference_golden(gpu_ready):
         assert np.array_equal(a[0], b[0]), "%s: hitpoint records differ" % name
         total += r["count"]
     assert total > 60000
+
+
+def test_progressive_accumulation(gpu_ready, orc):
+    """CGRT_GRID_ACCUMULATE: four passes of 2 samples added into one fp32 frame equal the single 8-sample launch
+    to fp32 rounding, and both match the oracle (row f4 of SURVEY.md section 8: replaces average.cpp)."""
+    import cgraytracing_amd as cg
+    import torch
+    sc = cg.Scene(scenes.scene_c3(True))
+    cam = scenes.cam_dof()
+    W, H, spp = 96, 96, 8
+    one, _, _ = sc.trace_grid(W, H, spp, cam, 5, 21)
+    acc = torch.zeros_like(one)
+    for p in range(4):
+        sc.trace_grid(W, H, 2, cam, 5, 21, sample_offset=2 * p, spp_total=spp, out=acc, accumulate=True)
+    torch.cuda.synchronize()
+    assert float((acc - one).abs().max()) < 2e-6
+    o = BackendScene(orc, scenes.scene_c3(True))
+    want = to_acc32(o.trace_grid(cam, W, H, spp, 5, 21)["acc_sum"], spp)
+    assert np.array_equal(one.cpu().numpy(), want)
+    assert np.abs(acc.cpu().numpy() - want).max() < 2e-6
+    sc.close()
