@@ -1,0 +1,13 @@
+"""Profiling driver (not a test): one mesh workload, a few launches.  rocprofv3 ... -- python3 tests/prof_mesh.py [dragon|bunny|bump]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import perf_probe as pp, scenes
+which = sys.argv[1] if len(sys.argv) > 1 else "dragon"
+if which == "dragon":
+    pp.run("dragon 2048 spp16", scenes.scene_dragon(), scenes.cam_dof(), 2048, 2048, 16, 5, reps=2)
+elif which == "bunny":
+    pp.run("bunny 2048 spp16", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 16, 5, reps=2)
+else:
+    tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    pp.run("bump 1024 spp4", scenes.planes(tex), scenes.cam_dof(), 1024, 1024, 4, 5, reps=2)
