@@ -1100,6 +1100,10 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
+    // launch on the scene's device whatever the caller's current device is (one host thread may drive several GPUs)
+    int caller_dev = s->device;
+    HIP_TRY(hipGetDevice(&caller_dev));
+    if (caller_dev != s->device) HIP_TRY(hipSetDevice(s->device));
     const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0, bez = s->dev.has_bezier != 0;
     const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
     const bool stats = (grid->flags & CGRT_GRID_STATS) != 0 && trees && !bez;
@@ -1122,7 +1126,9 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     }
 #undef LAUNCH_DG
 #undef LAUNCH
-    HIP_TRY(hipGetLastError());
+    const hipError_t launch_err = hipGetLastError();
+    if (caller_dev != s->device) (void)hipSetDevice(caller_dev);
+    if (launch_err != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(launch_err));
     return CGRT_OK;
 }
 
