@@ -326,68 +326,211 @@ __device__ __forceinline__ bool bez_box(const BezierRec &b, V3 o, V3 d) {
     return flag;
 }
 
-// Returns the Newton flag; len / n are written exactly as the reference writes them (n only when touched).
-__device__ bool bezier_intersect(const BezierRec &b, V3 pos, double cap_r, V3 o, V3 d, Stream rs, double &len, V3 &n) {
-    if (!bez_box(b, o, d)) return false;
+// One Newton iteration of newtonMethod (bezier.h:170-199) on the state (res, inverse columns, P, sin, cos, F).
+// Returns false when the Jacobian is singular (the caller decides what the reference's jitter branch means for it).
+struct NewtonState {
+    V3 res;         // (t, u, theta)
+    V3 iD, iE, iF;  // inverse columns, stale across singular steps
+    V3 P;           // valueP(u)
+    double sn, cs;  // sin(theta), cos(theta)
+    V3 fv;          // F(res)
+    int counter;
+};
+__device__ __forceinline__ double norm3(V3 v) { return sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+
+__device__ __forceinline__ void newton_init(const BezierRec &b, V3 pos, V3 o, V3 d, double u0, double t0, NewtonState &st) {
+    V3 pt = o + d * t0;
+    pt = pt - pos;
+    const double th0 = (pt.z < 0) ? 3.14159265 + atan(pt.x / pt.z) : atan(pt.x / pt.z);  // bezier.h:243-247
+    st.res = mk(t0, u0, th0);
+    st.iD = mk(0, 0, 0);
+    st.iE = mk(0, 0, 0);
+    st.iF = mk(0, 0, 0);
+    st.P = bez_value(b, st.res.y);
+    st.sn = sin(st.res.z);
+    st.cs = cos(st.res.z);
+    st.fv = ((o + d * st.res.x) - pos) - mk(st.P.z * st.sn, st.P.y, st.P.z * st.cs);  // funcValue, bezier.h:144-149
+    st.counter = 0;
+}
+// the Jacobian part: returns det and fills the inverse when regular
+__device__ __forceinline__ bool newton_jacobian(const BezierRec &b, V3 d, NewtonState &st) {
+    const V3 dP = bez_grad(b, st.res.y);
+    const V3 A = d;  // gradValue, bezier.h:150-162
+    const V3 B = mk(-st.sn * dP.z, -dP.y, -st.cs * dP.z);
+    const V3 C = mk(-st.cs * st.P.z, 0, st.sn * st.P.z);
+    const double dt = det3(A, B, C);  // inv(), vec3.h:103-119
+    if (dt < 1e-4 && dt > -1e-4) return false;
+    st.iD = mk((B.y * C.z - B.z * C.y) / dt, (C.y * A.z - C.z * A.y) / dt, (A.y * B.z - A.z * B.y) / dt);
+    st.iE = mk((C.x * B.z - C.z * B.x) / dt, (A.x * C.z - A.z * C.x) / dt, (B.x * A.z - B.z * A.x) / dt);
+    st.iF = mk((B.x * C.y - C.x * B.y) / dt, (C.x * A.y - C.y * A.x) / dt, (A.x * B.y - A.y * B.x) / dt);
+    return true;
+}
+__device__ __forceinline__ void newton_step(const BezierRec &b, V3 pos, V3 o, V3 d, NewtonState &st) {
+    const V3 step = (st.iD * st.fv.x + st.iE * st.fv.y) + st.iF * st.fv.z;  // matrixVectorProduct, vec3.h:99-101
+    st.res = st.res - step;
+    st.P = bez_value(b, st.res.y);
+    st.sn = sin(st.res.z);
+    st.cs = cos(st.res.z);
+    st.fv = ((o + d * st.res.x) - pos) - mk(st.P.z * st.sn, st.P.y, st.P.z * st.cs);
+}
+__device__ __forceinline__ bool newton_accept(const NewtonState &st) {  // bezier.h:257
+    return norm3(st.fv) < 1e-4 && st.res.x > 0 && st.res.y <= 1 && st.res.y >= 0;
+}
+__device__ __forceinline__ V3 bez_normal(const BezierRec &b, double u, double sn, double cs) {  // bezier.h:215-224
+    const V3 rp = normalized(bez_grad(b, u));
+    return mk(rp.y * sn, -rp.z, rp.y * cs);
+}
+
+// The ten solves of Bezier::intersect (bezier.h:233-271), one lane, strictly sequential draws: the reference's
+// exact semantics including the jitter branch.  Used by the function-level fallback below.
+__device__ bool bezier_solve_serial(const BezierRec &b, V3 pos, V3 o, V3 d, Stream rs, double &len, V3 &n) {
     bool flag = false;
     len = kInf;
     for (int k = 0; k < 10; k++) {  // num_of_samples_newton, bezier.h:27
         const double u0 = rs.u01();
         const double t0 = 20 + 10 * rs.u01();
-        V3 pt = o + d * t0;
-        pt = pt - pos;
-        const double th0 = (pt.z < 0) ? 3.14159265 + atan(pt.x / pt.z) : atan(pt.x / pt.z);  // bezier.h:243-247
-        // newtonMethod, bezier.h:163-214.  res = (t, u, theta)
-        V3 res = mk(t0, u0, th0);
-        V3 iD = mk(0, 0, 0), iE = mk(0, 0, 0), iF = mk(0, 0, 0);  // inverse columns, stale across singular steps
-        V3 P = bez_value(b, res.y);
-        double sn = sin(res.z), cs = cos(res.z);
-        V3 fv = ((o + d * res.x) - pos) - mk(P.z * sn, P.y, P.z * cs);  // funcValue, bezier.h:144-149
-        int counter = 0;
-        while (sqrt(fv.x * fv.x + fv.y * fv.y + fv.z * fv.z) > 1e-6 && counter < 100) {
-            counter++;
-            const V3 dP = bez_grad(b, res.y);
-            // gradValue, bezier.h:150-162
-            const V3 A = d;
-            const V3 B = mk(-sn * dP.z, -dP.y, -cs * dP.z);
-            const V3 C = mk(-cs * P.z, 0, sn * P.z);
-            const double dt = det3(A, B, C);  // inv(), vec3.h:103-119
-            if (dt < 1e-4 && dt > -1e-4) {
+        NewtonState st;
+        newton_init(b, pos, o, d, u0, t0, st);
+        while (norm3(st.fv) > 1e-6 && st.counter < 100) {
+            st.counter++;
+            if (!newton_jacobian(b, d, st)) {
                 // bezier.h:183: Vec3(u(),u(),u()) evaluates right to left under g++
                 const double uz = rs.u01(), uy = rs.u01(), ux = rs.u01();
-                res = mk(res.x + ux * 0.2 - 0.1, res.y + uy * 0.2 - 0.1, res.z + uz * 0.2 - 0.1);
-            } else {
-                iD = mk((B.y * C.z - B.z * C.y) / dt, (C.y * A.z - C.z * A.y) / dt, (A.y * B.z - A.z * B.y) / dt);
-                iE = mk((C.x * B.z - C.z * B.x) / dt, (A.x * C.z - A.z * C.x) / dt, (B.x * A.z - B.z * A.x) / dt);
-                iF = mk((B.x * C.y - C.x * B.y) / dt, (C.x * A.y - C.y * A.x) / dt, (A.x * B.y - A.y * B.x) / dt);
+                st.res = mk(st.res.x + ux * 0.2 - 0.1, st.res.y + uy * 0.2 - 0.1, st.res.z + uz * 0.2 - 0.1);
             }
-            const V3 step = (iD * fv.x + iE * fv.y) + iF * fv.z;  // matrixVectorProduct, vec3.h:99-101
-            res = res - step;
-            P = bez_value(b, res.y);
-            sn = sin(res.z);
-            cs = cos(res.z);
-            fv = ((o + d * res.x) - pos) - mk(P.z * sn, P.y, P.z * cs);
+            newton_step(b, pos, o, d, st);
         }
-        if (sqrt(fv.x * fv.x + fv.y * fv.y + fv.z * fv.z) < 1e-4 && res.x > 0 && res.y <= 1 && res.y >= 0) {
-            if (res.x < len) {
-                len = res.x;
-                const V3 rp = normalized(bez_grad(b, res.y));  // normalvec, bezier.h:215-224
-                n = mk(rp.y * sn, -rp.z, rp.y * cs);
-                flag = true;
-            }
-        }
-    }
-    n = (dot(n, d) < 0) ? n : -n;  // bezier.h:272
-    double newt = b.box[3] - o.y;  // ymax - rayorig.y, bezier.h:273-281
-    if (newt > 0.1) {
-        newt = newt / d.y;
-        const V3 np = o + d * newt;
-        if ((np.x - pos.x) * (np.x - pos.x) + (np.z - pos.z) * (np.z - pos.z) <= cap_r * cap_r) {
-            len = newt;
-            n = mk(0, 1, 0);
+        if (newton_accept(st) && st.res.x < len) {
+            len = st.res.x;
+            n = bez_normal(b, st.res.y, st.sn, st.cs);
+            flag = true;
         }
     }
     return flag;
+}
+
+// Wave-level form: the (ray, start) pairs of all lanes whose ray enters the Bezier box -- 10 Newton solves each,
+// 5 to 100 iterations apiece -- are dealt dynamically over all 64 lanes, so lanes whose own ray misses the box
+// (or has no ray at all) work on their neighbours' solves and a lane that converges early takes the next pair.
+// Per-lane serial solving costs the wave sum_k max_lanes(iterations); this costs about sum(iterations) / 64.
+//   * start k of a ray draws (u0, t0) from the ray's stream at draws 2k, 2k+1 = one splitmix output, which is
+//     what the sequential reference order gives as long as no earlier solve of that ray took the jitter branch;
+//   * a solve that meets a singular Jacobian flags its ray, and flagged rays are redone by bezier_solve_serial
+//     with the reference's exact sequential semantics (rare: |det J| < 1e-4);
+//   * results come back through per-wave LDS; the ray's lane then takes the nearest accepted root, first start
+//     winning ties (strict < in start order, bezier.h:260).
+// Must be called by all lanes of the wave in uniform control flow.
+static constexpr int kBezChunk = 32;  // rays whose solves are in flight together (results: 32 x 10 x 24 B per wave)
+struct BezLds {
+    double rt[kBezChunk * 10], ru[kBezChunk * 10], rth[kBezChunk * 10];
+    uint32_t singular[kBezChunk];
+    uint8_t lane_of_rank[64];
+};
+
+__device__ bool bezier_wave(const BezierRec &b, V3 pos, double cap_r, bool on, V3 o, V3 d, uint64_t key, double &len,
+                            V3 &n, volatile BezLds *L) {
+    const int lane = threadIdx.x & 63;
+    const bool want = on && bez_box(b, o, d);
+    const unsigned long long wm = __ballot(want);
+    if (wm == 0ull) return false;
+    const int nwant = __popcll(wm);
+    const int rank = __popcll(wm & ((1ull << lane) - 1ull));
+    if (want) L->lane_of_rank[rank] = (uint8_t)lane;
+    bool flag = false, redo = false;
+    len = kInf;
+    for (int base = 0; base < nwant; base += kBezChunk) {
+        const int nsrc = (nwant - base < kBezChunk) ? nwant - base : kBezChunk;
+        const int ntasks = nsrc * 10;
+        if (lane < kBezChunk) L->singular[lane] = 0u;
+        int next = 0;  // wave-uniform: first unassigned task
+        bool busy = false;
+        int task = 0;
+        V3 so = o, sd = d;
+        NewtonState st;
+        st.counter = 0;
+        st.fv = mk(0, 0, 0);
+        while (true) {
+            const unsigned long long fm = __ballot(!busy);
+            const int nfree = __popcll(fm), avail = ntasks - next;
+            // hand out tasks in batches (>= 8 lanes, or everything that is left) so that the solve set-up below
+            // runs with many lanes active rather than once per finishing lane
+            const int thresh = avail < 16 ? avail : 16;
+            if (avail > 0 && nfree >= thresh) {
+                const int r = __popcll(fm & ((1ull << lane) - 1ull));
+                const bool take = !busy && r < avail;
+                const int t = next + r;
+                next += (nfree < avail) ? nfree : avail;
+                const int src = take ? (int)L->lane_of_rank[base + t / 10] : lane;
+                // every lane executes the shuffles (a disabled source lane would read as zero)
+                const V3 fo = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                const V3 fd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                const unsigned long long fkey = __shfl((unsigned long long)key, src);
+                if (take) {
+                    so = fo;
+                    sd = fd;
+                    task = t;
+                    const uint64_t z = fin64(fkey + (uint64_t)(t % 10 + 1) * kGolden);
+                    const double u0 = div_rand_max((uint32_t)(z >> 33));
+                    const double t0 = 20 + 10 * div_rand_max((uint32_t)((z >> 2) & 0x7fffffffu));
+                    newton_init(b, pos, so, sd, u0, t0, st);
+                    busy = true;
+                }
+            }
+            if (__ballot(busy) == 0ull) break;
+            if (busy) {
+                if (norm3(st.fv) > 1e-6 && st.counter < 100) {
+                    st.counter++;
+                    if (newton_jacobian(b, sd, st)) {
+                        newton_step(b, pos, so, sd, st);
+                    } else {
+                        L->singular[task / 10] = 1u;  // this ray needs the sequential semantics
+                        L->rt[task] = kInf;
+                        busy = false;
+                    }
+                } else {
+                    const bool acc = newton_accept(st);
+                    L->rt[task] = acc ? st.res.x : kInf;
+                    L->ru[task] = st.res.y;
+                    L->rth[task] = st.res.z;
+                    busy = false;
+                }
+            }
+        }
+        if (want && rank >= base && rank < base + nsrc) {
+            const int sl = rank - base;
+            if (L->singular[sl] != 0u) {
+                redo = true;
+            } else {
+                int bk = -1;
+                for (int k = 0; k < 10; k++) {
+                    const double t = L->rt[sl * 10 + k];
+                    if (t < len) {
+                        len = t;
+                        bk = k;
+                    }
+                }
+                if (bk >= 0) {
+                    const double th = L->rth[sl * 10 + bk];
+                    n = bez_normal(b, L->ru[sl * 10 + bk], sin(th), cos(th));
+                    flag = true;
+                }
+            }
+        }
+    }
+    if (redo) flag = bezier_solve_serial(b, pos, o, d, Stream(key), len, n);
+    if (want) {
+        n = (dot(n, d) < 0) ? n : -n;  // bezier.h:272
+        double newt = b.box[3] - o.y;  // ymax - rayorig.y, bezier.h:273-281
+        if (newt > 0.1) {
+            newt = newt / d.y;
+            const V3 np = o + d * newt;
+            if ((np.x - pos.x) * (np.x - pos.x) + (np.z - pos.z) * (np.z - pos.z) <= cap_r * cap_r) {
+                len = newt;
+                n = mk(0, 1, 0);
+            }
+        }
+    }
+    return want && flag;
 }
 
 // =====================================================================================================
@@ -442,7 +585,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, int tr, bool 
 
 template <bool TREES, bool BEZ, bool SPH, bool STATS>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
-                                                    V3 o, V3 d, const RayKey &rk, bool on,
+                                                    V3 o, V3 d, const RayKey &rk, bool on, volatile BezLds *bl,
                                                     uint32_t &n_node, uint32_t &n_tri) {
     SceneHit best;
     best.t = kInf;  // `nearest = INF`, main.cpp:54
@@ -513,10 +656,10 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             }
         } else if (BEZ && kind == KIND_BEZIER) {
             const BezierRec &bz = sc.beziers[__builtin_amdgcn_readfirstlane(ob.aux)];
-            Stream rs(rk.explicit_key ? rk.k : purpose_key(rk.k, ((uint64_t)rk.path << 16) | (uint64_t)(i + 1)));
+            const uint64_t key = rk.explicit_key ? rk.k : purpose_key(rk.k, ((uint64_t)rk.path << 16) | (uint64_t)(i + 1));
             double len = 0;
             V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
-            if (on && bezier_intersect(bz, ld3(ob.a), ob.b[0], o, d, rs, len, nrm)) {
+            if (bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, len, nrm, bl)) {
                 if (len < best.t) {
                     best.t = len;
                     best.id = i;
@@ -561,6 +704,10 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float *ltile = reinterpret_cast<float *>(lds_raw);
     ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? kStackBytes : kTileBytes));  // n_objs records
+    // BEZ: one BezLds per wave behind the object list (16-byte aligned: ObjRec is 128 B)
+    volatile BezLds *bl =
+        BEZ ? reinterpret_cast<volatile BezLds *>(reinterpret_cast<unsigned char *>(lobjs + sc.n_objs)) + (threadIdx.x >> 6)
+            : nullptr;
 
     // stage the primitive list in LDS (128 B records, copied as 16-byte pieces)
     {
@@ -639,7 +786,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
         // is wave-uniform, so its control flow stays scalar.
         const RayKey rk{k_smp, path, false};
         const SceneHit hit =
-            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, my_nodes, my_tris);
+            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, bl, my_nodes, my_tris);
         if (have) {
             my_rays++;
             have = false;
@@ -818,13 +965,16 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
                                       const double *__restrict__ dir, const unsigned long long *__restrict__ keys,
                                       int n, int32_t *__restrict__ hit,
                                       double *__restrict__ len, double *__restrict__ nrm) {
+    __shared__ BezLds bl;  // blockDim.x == 64: one wave per block
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool on = i < n;
+    const int ii = on ? i : 0;
     uint32_t a = 0, b = 0;
-    const V3 o = ld3(org + 3 * i), d = ld3(dir + 3 * i);
+    const V3 o = ld3(org + 3 * ii), d = ld3(dir + 3 * ii);
     DeviceScene one = sc;
-    const RayKey rk{keys ? keys[i] : 0ull, 1, true};
-    SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, one, o, d, rk, true, a, b);
+    const RayKey rk{keys ? keys[ii] : 0ull, 1, true};
+    SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, one, o, d, rk, on, &bl, a, b);
+    if (!on) return;
     hit[i] = h.id >= 0 ? 1 : 0;
     len[i] = h.t;
     nrm[3 * i] = h.n.x;
@@ -1108,6 +1258,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
     const bool stats = (grid->flags & CGRT_GRID_STATS) != 0 && trees && !bez;
     lds += glass ? kStackBytes : kTileBytes;
+    if (bez) lds += (kThreads / 64) * sizeof(BezLds);
 #define LAUNCH(T, B, D, G, P, S) \
     hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
 #define LAUNCH_DG(T, B, P, S)                                      \
@@ -1157,7 +1308,7 @@ int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const
     HIP_TRY(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
     const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
     const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
-    const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec) + kStackBytes;
+    const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec) + kStackBytes + (kThreads / 64) * sizeof(BezLds);
     HitpointSink sink{d_rec, d_cnt, (unsigned long long)cap};
     // the most general variant serves every scene; capture is a verification / hand-off path, not the hot path
     if (cam->lens_radius > 0)
