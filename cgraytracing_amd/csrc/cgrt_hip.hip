@@ -568,11 +568,21 @@ __device__ __forceinline__ double sphere_len(const ObjRec &ob, V3 o, V3 d) {
     return len;
 }
 
+// One small tree (<= kNodeCache nodes: the bunny's 255, a coarse bump floor) is staged whole in LDS by every workgroup:
+// traversal is latency-bound on dependent node fetches, and an LDS read costs ~100 cycles against ~500-800 for L1/L2.
+static constexpr int kNodeCache = 256;  // 8 KiB of 32-byte nodes
+
+// per-workgroup LDS resources handed down to the scene walk
+struct LdsAux {
+    volatile BezLds *bl;    // this wave's Bezier scratch (BEZ variants) or nullptr
+    const NodeRec *lnodes;  // LDS copy of tree sc.cached_tree's nodes, or nullptr
+};
+
 // tree traversal entry; `on` = this lane really has a ray for this tree (all lanes of the wave call it).
 // A wave-synchronous variant (one shared node sequence, records fetched through the scalar cache) was measured
 // and dropped: with sub-pixel triangles the union of 64 rays' leaf sets approaches their sum.
 template <bool STATS>
-__device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, int tr, bool on, V3 o, V3 d, V3 inv,
+__device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux &aux, int tr, bool on, V3 o, V3 d, V3 inv,
                                             uint32_t &n_node, uint32_t &n_tri) {
     const TreeRec T = sc.trees[tr];
     TreeHit none;
@@ -580,12 +590,14 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, int tr, bool 
     none.tri = -1;
     none.counter = 0;
     if (!on) return none;
+    if (aux.lnodes != nullptr && tr == sc.cached_tree)
+        return tree_intersect<STATS>(aux.lnodes, sc.tris + T.tri_begin, T.nnodes, o, d, inv, n_node, n_tri);
     return tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d, inv, n_node, n_tri);
 }
 
 template <bool TREES, bool BEZ, bool SPH, bool STATS>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
-                                                    V3 o, V3 d, const RayKey &rk, bool on, volatile BezLds *bl,
+                                                    V3 o, V3 d, const RayKey &rk, bool on, const LdsAux &aux,
                                                     uint32_t &n_node, uint32_t &n_tri) {
     SceneHit best;
     best.t = kInf;  // `nearest = INF`, main.cpp:54
@@ -627,7 +639,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
                 const bool want = on && ph;  // the bump tree is only consulted when the plane is hit (objects.h:508-513)
                 if (tr >= 0 && __ballot(want) != 0ull) {
-                    const TreeHit h = tree_hit<STATS>(sc, tr, want, o, d, inv, n_node, n_tri);
+                    const TreeHit h = tree_hit<STATS>(sc, aux, tr, want, o, d, inv, n_node, n_tri);
                     if (want && h.counter > 0 && h.len < len && h.len > 0) {
                         len = h.len;
                         nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
@@ -644,7 +656,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             // TriangleMesh::intersect, objects.h:405-455
             const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
             if (__ballot(on) != 0ull) {
-                const TreeHit h = tree_hit<STATS>(sc, tr, on, o, d, inv, n_node, n_tri);
+                const TreeHit h = tree_hit<STATS>(sc, aux, tr, on, o, d, inv, n_node, n_tri);
                 if (on && h.counter > 0 && h.len < best.t) {
                     V3 nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
                     if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436
@@ -659,7 +671,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             const uint64_t key = rk.explicit_key ? rk.k : purpose_key(rk.k, ((uint64_t)rk.path << 16) | (uint64_t)(i + 1));
             double len = 0;
             V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
-            if (bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, len, nrm, bl)) {
+            if (bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, len, nrm, aux.bl)) {
                 if (len < best.t) {
                     best.t = len;
                     best.id = i;
@@ -705,9 +717,19 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
     float *ltile = reinterpret_cast<float *>(lds_raw);
     ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? kStackBytes : kTileBytes));  // n_objs records
     // BEZ: one BezLds per wave behind the object list (16-byte aligned: ObjRec is 128 B)
-    volatile BezLds *bl =
-        BEZ ? reinterpret_cast<volatile BezLds *>(reinterpret_cast<unsigned char *>(lobjs + sc.n_objs)) + (threadIdx.x >> 6)
-            : nullptr;
+    unsigned char *lrest = reinterpret_cast<unsigned char *>(lobjs + sc.n_objs);
+    LdsAux aux;
+    aux.bl = BEZ ? reinterpret_cast<volatile BezLds *>(lrest) + (threadIdx.x >> 6) : nullptr;
+    if (BEZ) lrest += (kThreads / 64) * sizeof(BezLds);
+    // TREES: node cache behind that (32-byte records, region is 16-byte aligned)
+    NodeRec *lnodes = reinterpret_cast<NodeRec *>(lrest);
+    aux.lnodes = (TREES && sc.cached_tree >= 0) ? lnodes : nullptr;
+    if (TREES && sc.cached_tree >= 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes + sc.trees[sc.cached_tree].node_begin);
+        uint4 *dst = reinterpret_cast<uint4 *>(lnodes);
+        const int n16 = sc.cached_nodes * (int)(sizeof(NodeRec) / 16);
+        for (int k = threadIdx.x; k < n16; k += kThreads) dst[k] = src[k];
+    }
 
     // stage the primitive list in LDS (128 B records, copied as 16-byte pieces)
     {
@@ -786,7 +808,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
         // is wave-uniform, so its control flow stays scalar.
         const RayKey rk{k_smp, path, false};
         const SceneHit hit =
-            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, bl, my_nodes, my_tris);
+            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
         if (have) {
             my_rays++;
             have = false;
@@ -973,7 +995,8 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     const V3 o = ld3(org + 3 * ii), d = ld3(dir + 3 * ii);
     DeviceScene one = sc;
     const RayKey rk{keys ? keys[ii] : 0ull, 1, true};
-    SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, one, o, d, rk, on, &bl, a, b);
+    const LdsAux aux{&bl, nullptr};
+    SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, one, o, d, rk, on, aux, a, b);
     if (!on) return;
     hit[i] = h.id >= 0 ? 1 : 0;
     len[i] = h.t;
@@ -1148,6 +1171,14 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     d.n_beziers = (int32_t)H.beziers.size();
     d.has_mesh = trees.empty() ? 0 : 1;
     d.has_bezier = H.beziers.empty() ? 0 : 1;
+    d.cached_tree = -1;
+    d.cached_nodes = 0;
+    for (size_t t = 0; t < trees.size(); t++)
+        if (trees[t].nnodes > 0 && trees[t].nnodes <= kNodeCache) {  // first tree small enough to live in LDS
+            d.cached_tree = (int32_t)t;
+            d.cached_nodes = trees[t].nnodes;
+            break;
+        }
     d.all_spheres = 1;
     d.has_glass = 0;
     for (auto &o : H.objs) {
@@ -1259,6 +1290,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const bool stats = (grid->flags & CGRT_GRID_STATS) != 0 && trees && !bez;
     lds += glass ? kStackBytes : kTileBytes;
     if (bez) lds += (kThreads / 64) * sizeof(BezLds);
+    if (trees && s->dev.cached_tree >= 0) lds += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
 #define LAUNCH(T, B, D, G, P, S) \
     hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
 #define LAUNCH_DG(T, B, P, S)                                      \
@@ -1308,7 +1340,8 @@ int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const
     HIP_TRY(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
     const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
     const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
-    const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec) + kStackBytes + (kThreads / 64) * sizeof(BezLds);
+    const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec) + kStackBytes + (kThreads / 64) * sizeof(BezLds) +
+                       (s->dev.cached_tree >= 0 ? (size_t)s->dev.cached_nodes * sizeof(NodeRec) : 0);
     HitpointSink sink{d_rec, d_cnt, (unsigned long long)cap};
     // the most general variant serves every scene; capture is a verification / hand-off path, not the hot path
     if (cam->lens_radius > 0)

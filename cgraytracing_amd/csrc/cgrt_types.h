@@ -94,6 +94,8 @@ struct DeviceScene {
     int32_t has_bezier;
     int32_t all_spheres; // fast path selector
     int32_t has_glass;   // some object takes the refraction branch (main.cpp:135)
+    int32_t cached_tree; // tree whose nodes every workgroup stages in LDS (-1: none)
+    int32_t cached_nodes;
 };
 
 }  // namespace cgrt
