@@ -175,9 +175,13 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
         double leaf_len = kInf;
         int leaf_tri = -1, leaf_cnt = 0;
         const TriRec *tp = tris + leaf_begin;
+        // one triangle ahead: the next record is requested before the current one is tested (every request is used
+        // except the repeat of the last one, so this adds no traffic)
+        V3 pa = ld3(tp[0].pa), e1 = ld3(tp[0].e1), e2 = ld3(tp[0].e2);
         for (int k = 0; k < leaf_cnt_tris; k++) {
             if (STATS) n_tri++;
-            const V3 pa = ld3(tp[k].pa), e1 = ld3(tp[k].e1), e2 = ld3(tp[k].e2);
+            const int kn = (k + 1 < leaf_cnt_tris) ? k + 1 : k;
+            const V3 npa = ld3(tp[kn].pa), ne1 = ld3(tp[kn].e1), ne2 = ld3(tp[kn].e2);
             const V3 s = pa - o;
             const double det1 = det3(d, e1, e2);
             const double det2 = det3(s, e1, e2);
@@ -195,6 +199,9 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
                     leaf_cnt++;
                 }
             }
+            pa = npa;
+            e1 = ne1;
+            e2 = ne2;
         }
         if (leaf_cnt > 0) {
             // objects.h:295-313: the left result survives only if strictly nearer => later leaf wins ties
