@@ -178,13 +178,22 @@ def main():
         # algorithmic HBM bytes of one launch on one GPU: fp32 RGB store + scene read once
         alg_bytes = 12 * W * rows_local + stats["scene_bytes_fp64"]
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if n == 1 and os.path.exists(tpath):
+        # PMC figures come from the committed rocprofv3 passes of this same command (profiles/r01_pmc.json):
+        # HBM bytes per launch, and -- because the binding resource is fp64 VALU issue, not HBM -- how busy the VALUs were
+        traffic, valu = None, None
+        ppath = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if n == 1 and os.path.exists(ppath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                prof = json.load(open(ppath))
+                traffic = prof.get("hbm_bytes_per_launch")
+                cn = prof["counters"]
+                simd_cycles = 1024 * cn["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+                valu = {"busy_frac": round(4.0 * cn["SQ_ACTIVE_INST_VALU"]["mean"] / simd_cycles, 3),
+                        "lanes_active_frac": round(cn["SQ_THREAD_CYCLES_VALU"]["mean"] /
+                                                   (64.0 * cn["SQ_ACTIVE_INST_VALU"]["mean"]), 3),
+                        "wave_insts_per_launch": int(cn["SQ_INSTS_VALU"]["mean"]), "source": "profiles/r01_pmc.json"}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         line = {
             "metric": "Mrays/sec (primary+secondary) at 1920x1080 spp=64",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -200,7 +209,8 @@ def main():
                          "algorithmic_bytes": int(alg_bytes),
                          "note": "FP64-VALU/divergence bound by design (SURVEY.md §8d H5); HBM fraction reported as required",
                          "kernel_mrays_per_s": round(rays_per_step / n / (kern_ms * 1e-3) / 1e6, 2),
-                         "lane_utilisation": round(total_rays / max(1, 64 * int(cnt[2].item())), 4)},
+                         "lane_utilisation": round(total_rays / max(1, 64 * int(cnt[2].item())), 4),
+                         "valu": valu},
         }
         if args.cpu_spp > 0:
             base, _ = cpu_baseline(args.cpu_spp)

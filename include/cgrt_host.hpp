@@ -52,6 +52,15 @@ inline double det(const Vec3 &a, const Vec3 &b, const Vec3 &c) {
 inline Vec3 matrixVectorProduct(const Vec3 &a, const Vec3 &b, const Vec3 &c, const Vec3 &d) {
     return a * d.x + b * d.y + c * d.z;
 }
+// adjugate / determinant, "singular" when |det| < 1e-4 (vec3.h:103-119)
+inline bool inv(const Vec3 &a, const Vec3 &b, const Vec3 &c, Vec3 &resa, Vec3 &resb, Vec3 &resc) {
+    const double d = det(a, b, c);
+    if (d < 1e-4 && d > -1e-4) return false;
+    resa = Vec3((b.y * c.z - b.z * c.y) / d, (c.y * a.z - c.z * a.y) / d, (a.y * b.z - a.z * b.y) / d);
+    resb = Vec3((c.x * b.z - c.z * b.x) / d, (a.x * c.z - a.z * c.x) / d, (b.x * a.z - b.z * a.x) / d);
+    resc = Vec3((b.x * c.y - c.x * b.y) / d, (c.x * a.y - c.y * a.x) / d, (a.x * b.y - a.y * b.x) / d);
+    return true;
+}
 
 struct Error : std::runtime_error {
     int code;

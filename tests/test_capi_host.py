@@ -123,3 +123,38 @@ def test_product_never_touches_the_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "liborc" not in txt and "oracle/" not in txt.replace("oracle/).", ""), os.path.join(dp, f)
                 assert "backends" not in txt
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/cgrt.h compiles as strict C99 and the C caller links against libcgrt.so."""
+    import subprocess
+    from cgraytracing_amd import _capi
+    src = os.path.join(ROOT, "tests", "native", "abi_c99.c")
+    obj = str(tmp_path / "abi.o")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", src, "-o", obj])
+    so = str(tmp_path / "libabi.so")
+    subprocess.check_call(["gcc", "-shared", "-o", so, obj, "-L", os.path.dirname(_capi.LIB_PATH), "-lcgrt",
+                           "-Wl,-rpath," + os.path.dirname(_capi.LIB_PATH)])
+    assert C.CDLL(so).cgrt_abi_smoke() == 0
+
+
+def test_host_builder_under_sanitizers(tmp_path):
+    """Loaders, bump-mesh construction and tree build (cgrt_build.cpp) run clean under ASan + UBSan (CPU build;
+    GPU sanitizers are not available on the pool)."""
+    import subprocess
+    exe = str(tmp_path / "build_san")
+    csrc = os.path.join(ROOT, "cgraytracing_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", csrc, os.path.join(ROOT, "tests", "native", "build_san.cpp"),
+                           os.path.join(csrc, "cgrt_build.cpp"), "-o", exe])
+    bad = tmp_path / "bad.txt"
+    bad.write_text("3\nv 0 0 0\nv 1 0 0\n")
+    assets = os.path.join(GOLD, "assets")
+    out = subprocess.run([exe, os.path.join(assets, "mesh_t0.txt"), "0", os.path.join(assets, "mesh_t1.txt"), "1",
+                          os.path.join(assets, "mesh_t2.txt"), "2", str(bad), "1", str(tmp_path / "missing.txt"), "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ERROR" not in out.stderr and "runtime error" not in out.stderr
+    assert "bad.txt -> -2" in out.stdout  # malformed file refused
+    assert "missing.txt -> " in out.stdout and "objs=" in out.stdout
