@@ -126,9 +126,19 @@ struct TreeHit {
     int counter;  // improvements (Q5)
 };
 
-template <bool STATS>
+//
+// PRUNE (opaque objects only).  The improvement counter only decides the SIGN of the returned normal, and trace()
+// re-orients the normal against the ray for every material (main.cpp:73-76); diffuse and mirror shading use
+// nothing else of it, so for an object whose transparency is < eps the counter cannot influence the image or
+// the Hitpoint records (the one exception is a ray exactly tangent to the winning triangle,
+// n.d == 0, where no re-orientation happens).  Then only the nearest hit matters, and a subtree whose box the
+// ray enters beyond `bound` -- the nearest hit known so far, in this tree or among the objects tested before
+// it -- can be skipped: a hit inside it would lose the strict `len < nearest` tests (objects.h:281,297;
+// main.cpp:57).  Entry distances come from the grown, outward-rounded boxes, so they never exceed the true
+// ones and a leaf holding a triangle that ties with the bound is still scanned: (len, triangle) stay exact.
+template <bool STATS, bool PRUNE>
 __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ nodes, const TriRec *__restrict__ tris,
-                                                  int nnodes, V3 o, V3 d, V3 inv, uint32_t &n_node,
+                                                  int nnodes, V3 o, V3 d, V3 inv, double bound, uint32_t &n_node,
                                                   uint32_t &n_tri) {
     TreeHit r;
     r.len = kInf;
@@ -158,7 +168,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             t2 = ((double)q1.y - o.z) * inv.z;
             tn = fmax(tn, fmin(t1, t2));
             tf = fmin(tf, fmax(t1, t2));
-            const bool touch = (tf > 0.0) && (tn <= tf);
+            const bool touch = (tf > 0.0) && (tn <= tf) && !(PRUNE && tn > bound);
             const int leaf = __float_as_int(q1.w);
             if (!touch) {
                 i = __float_as_int(q1.z);
@@ -210,6 +220,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
                 r.tri = leaf_tri;
             }
             r.counter += leaf_cnt;
+            if (PRUNE && r.len < bound) bound = r.len;
         }
     }
     return r;
@@ -588,18 +599,26 @@ struct LdsAux {
 // tree traversal entry; `on` = this lane really has a ray for this tree (all lanes of the wave call it).
 // A wave-synchronous variant (one shared node sequence, records fetched through the scalar cache) was measured
 // and dropped: with sub-pixel triangles the union of 64 rays' leaf sets approaches their sum.
+// `opaque` (wave-uniform): the owning object's transparency is < eps, so the pruned traversal applies with
+// `bound` = nearest hit distance already known for this ray.
 template <bool STATS>
-__device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux &aux, int tr, bool on, V3 o, V3 d, V3 inv,
-                                            uint32_t &n_node, uint32_t &n_tri) {
+__device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux &aux, int tr, bool opaque, double bound,
+                                            bool on, V3 o, V3 d, V3 inv, uint32_t &n_node, uint32_t &n_tri) {
     const TreeRec T = sc.trees[tr];
     TreeHit none;
     none.len = kInf;
     none.tri = -1;
     none.counter = 0;
     if (!on) return none;
-    if (aux.lnodes != nullptr && tr == sc.cached_tree)
-        return tree_intersect<STATS>(aux.lnodes, sc.tris + T.tri_begin, T.nnodes, o, d, inv, n_node, n_tri);
-    return tree_intersect<STATS>(sc.nodes + T.node_begin, sc.tris + T.tri_begin, T.nnodes, o, d, inv, n_node, n_tri);
+    const bool cached = aux.lnodes != nullptr && tr == sc.cached_tree;
+    const NodeRec *nodes = sc.nodes + T.node_begin;
+    const TriRec *tris = sc.tris + T.tri_begin;
+    if (opaque) {
+        if (cached) return tree_intersect<STATS, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+        return tree_intersect<STATS, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+    }
+    if (cached) return tree_intersect<STATS, false>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+    return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
 }
 
 template <bool TREES, bool BEZ, bool SPH, bool STATS>
@@ -646,7 +665,10 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
                 const bool want = on && ph;  // the bump tree is only consulted when the plane is hit (objects.h:508-513)
                 if (tr >= 0 && __ballot(want) != 0ull) {
-                    const TreeHit h = tree_hit<STATS>(sc, aux, tr, want, o, d, inv, n_node, n_tri);
+                    // a bump hit only counts if it is nearer than the plane itself (objects.h:514) and, to matter,
+                    // nearer than the nearest object so far
+                    const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
+                    const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, fmin(len, best.t), want, o, d, inv, n_node, n_tri);
                     if (want && h.counter > 0 && h.len < len && h.len > 0) {
                         len = h.len;
                         nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
@@ -663,7 +685,8 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             // TriangleMesh::intersect, objects.h:405-455
             const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
             if (__ballot(on) != 0ull) {
-                const TreeHit h = tree_hit<STATS>(sc, aux, tr, on, o, d, inv, n_node, n_tri);
+                const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
+                const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, best.t, on, o, d, inv, n_node, n_tri);
                 if (on && h.counter > 0 && h.len < best.t) {
                     V3 nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
                     if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436
