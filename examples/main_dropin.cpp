@@ -2,7 +2,7 @@
 // reference's constructor signatures, pushed into `vector<Object*> objs` in the reference's order (spheres,
 // planes, meshes, Bezier; main.cpp:355-378) and handed to render(objs).  The per-pixel work runs on the GPU.
 //
-//   cgrt_main [--scene c2|planes|mesh FILE TYPE] [--width W] [--height H] [--spp N] [--dof] [--depth D]
+//   cgrt_main [--scene c2|planes|chess|vase] [--mesh FILE TYPE] [--width W] [--height H] [--spp N] [--dof] [--depth D]
 //             [--raw out.f32] [--ppm out.ppm]
 #include <cmath>
 #include <cstdio>
@@ -49,7 +49,25 @@ int main(int argc, char *argv[]) {
         sphs.push_back(Sphere(Vec3(10.0, -13.0, 30), 7, Vec3(1.0, 1.0, 1.0), 0.8, 0.0));
         sphs.push_back(Sphere(Vec3(-8.0, -13.0, 25), 7, Vec3(1.0, 1.0, 1.0), 0.8, 0.5));
     } else {
-        plns.push_back(Plane(Vec3(0.0, -20, 0), Vec3(0, 1, 0), Vec3(0.15, 0.15, 0.15), 0.0, 0.0));
+        Texture tex;  // default: untextured floor (main.cpp:349-353 style planes)
+        if (scene == "chess") {
+            // a procedural 64x64 checker decoded the way main.cpp:303-316 decodes an image: byte / 256 per channel
+            vector<vector<Vec3> > tdata;
+            for (int i = 0; i < 64; i++) {
+                vector<Vec3> row;
+                for (int j = 0; j < 64; j++) {
+                    const unsigned char v = (((i / 8) + (j / 8)) & 1) ? 230 : 25;
+                    Vec3 col;
+                    col.x = (double)v / (double)256;
+                    col.y = (double)(unsigned char)(v / 2 + 60) / (double)256;
+                    col.z = (double)(unsigned char)(255 - v) / (double)256;
+                    row.push_back(col);
+                }
+                tdata.push_back(row);
+            }
+            tex = Texture(tdata, Vec3(0, 1, 0), Vec3(-21, 0, 0), 42, 40, true);  // bump-mapped, like main.cpp:320
+        }
+        plns.push_back(Plane(Vec3(0.0, -20, 0), Vec3(0, 1, 0), Vec3(0.15, 0.15, 0.15), 0.0, 0.0, tex));
         plns.push_back(Plane(Vec3(20, 0.0, 0), Vec3(-1, 0, 0), Vec3(0.15, 0.50, 0.15), 0.0, 0.0));
         plns.push_back(Plane(Vec3(-20, 0.0, 0), Vec3(1, 0, 0), Vec3(0.50, 0.15, 0.15), 0.0, 0.0));
         plns.push_back(Plane(Vec3(0.0, 0.0, 40), Vec3(0, 0, -1), Vec3(0.15, 0.15, 0.15), 0.0, 0.0));

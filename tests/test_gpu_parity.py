@@ -165,6 +165,17 @@ def test_cpp_host_program_dropin(gpu_ready, orc, tmp_path):
     g = np.load(os.path.join(GOLD, "loader_t0.npz"))
     got2 = np.fromfile(raw2, np.float32).reshape(48, 48, 3)
     assert np.array_equal(got2, to_acc32(g["acc_sum"], 1))
+    # a textured, bump-mapped floor built from vector<vector<Vec3>> texels (byte/256), plus the Bezier vase
+    raw3 = str(tmp_path / "chess.f32")
+    subprocess.run([exe, "--scene", "chess", "--width", "80", "--height", "60", "--spp", "2", "--dof", "--raw", raw3],
+                   capture_output=True, text=True, check=True)
+    v = np.where((((np.arange(64)[:, None] // 8) + (np.arange(64)[None, :] // 8)) & 1) == 1, 230, 25).astype(np.uint8)
+    rgb = np.stack([v, (v // 2 + 60).astype(np.uint8), (255 - v).astype(np.uint8)], -1)
+    tex = scenes.Texture(np.ascontiguousarray(rgb), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    o3 = BackendScene(orc, scenes.planes(tex))
+    want3 = o3.trace_grid(scenes.cam_dof(), 80, 60, 2, 5, seed=12345)
+    got3 = np.fromfile(raw3, np.float32).reshape(60, 80, 3)
+    assert np.array_equal(got3, to_acc32(want3["acc_sum"], 2))
 
 
 def _canon(hp, pix, smp):
