@@ -365,8 +365,7 @@ __device__ __forceinline__ void newton_init(const BezierRec &b, V3 pos, V3 o, V3
     st.iE = mk(0, 0, 0);
     st.iF = mk(0, 0, 0);
     st.P = bez_value(b, st.res.y);
-    st.sn = sin(st.res.z);
-    st.cs = cos(st.res.z);
+    sincos(st.res.z, &st.sn, &st.cs);
     st.fv = ((o + d * st.res.x) - pos) - mk(st.P.z * st.sn, st.P.y, st.P.z * st.cs);  // funcValue, bezier.h:144-149
     st.counter = 0;
 }
@@ -378,17 +377,30 @@ __device__ __forceinline__ bool newton_jacobian(const BezierRec &b, V3 d, Newton
     const V3 C = mk(-st.cs * st.P.z, 0, st.sn * st.P.z);
     const double dt = det3(A, B, C);  // inv(), vec3.h:103-119
     if (dt < 1e-4 && dt > -1e-4) return false;
-    st.iD = mk((B.y * C.z - B.z * C.y) / dt, (C.y * A.z - C.z * A.y) / dt, (A.y * B.z - A.z * B.y) / dt);
-    st.iE = mk((C.x * B.z - C.z * B.x) / dt, (A.x * C.z - A.z * C.x) / dt, (B.x * A.z - B.z * A.x) / dt);
-    st.iF = mk((B.x * C.y - C.x * B.y) / dt, (C.x * A.y - C.y * A.x) / dt, (A.x * B.y - A.y * B.x) / dt);
+    // Nine quotients by the same determinant.  hipcc expands every fp64 `x / dt` into: r0 = v_rcp_f64(dt), two
+    // Newton refinements of r, q0 = x*r, e = fma(-dt, q0, x), q = fma(e, r, q0) (plus operand scaling that is the
+    // identity unless an exponent is extreme).  Sharing the refined reciprocal and keeping the per-quotient part
+    // gives the same correctly rounded quotients for 1e-4 <= |dt| and ordinary numerators at 3 instead of ~13
+    // instructions each; a numerator that has already overflowed (a diverged solve, rejected either way) is handed
+    // to a true division.
+    double rc = __builtin_amdgcn_rcp(dt);
+    rc = fma(fma(-dt, rc, 1.0), rc, rc);
+    rc = fma(fma(-dt, rc, 1.0), rc, rc);
+    auto quot = [&](double x) {
+        const double q0 = x * rc;
+        const double q = fma(fma(-dt, q0, x), rc, q0);
+        return (fabs(x) < 1e300) ? q : x / dt;
+    };
+    st.iD = mk(quot(B.y * C.z - B.z * C.y), quot(C.y * A.z - C.z * A.y), quot(A.y * B.z - A.z * B.y));
+    st.iE = mk(quot(C.x * B.z - C.z * B.x), quot(A.x * C.z - A.z * C.x), quot(B.x * A.z - B.z * A.x));
+    st.iF = mk(quot(B.x * C.y - C.x * B.y), quot(C.x * A.y - C.y * A.x), quot(A.x * B.y - A.y * B.x));
     return true;
 }
 __device__ __forceinline__ void newton_step(const BezierRec &b, V3 pos, V3 o, V3 d, NewtonState &st) {
     const V3 step = (st.iD * st.fv.x + st.iE * st.fv.y) + st.iF * st.fv.z;  // matrixVectorProduct, vec3.h:99-101
     st.res = st.res - step;
     st.P = bez_value(b, st.res.y);
-    st.sn = sin(st.res.z);
-    st.cs = cos(st.res.z);
+    sincos(st.res.z, &st.sn, &st.cs);  // one shared argument reduction; same values as sin() and cos()
     st.fv = ((o + d * st.res.x) - pos) - mk(st.P.z * st.sn, st.P.y, st.P.z * st.cs);
 }
 __device__ __forceinline__ bool newton_accept(const NewtonState &st) {  // bezier.h:257
