@@ -228,3 +228,32 @@ def test_progressive_accumulation(gpu_ready, orc):
     assert np.array_equal(one.cpu().numpy(), want)
     assert np.abs(acc.cpu().numpy() - want).max() < 2e-6
     sc.close()
+
+
+def test_everything_at_once(gpu_ready, orc):
+    """One scene with every object kind and material: glass + mirror + diffuse spheres, textured bump floor, a glass
+    mesh (LDS-cached tree), an opaque mesh (pruned traversal), the Bezier vase; thin lens, depth 5.  Exercises the
+    most general kernel variant (TREES, BEZ, DOF, GLASS) and its largest LDS carve-up."""
+    import cgraytracing_amd as cg
+    objs = [scenes.Sphere((-12.0, -14.0, 32), 5, (1.0, 1.0, 1.0), 0.8, 0.5),
+            scenes.Sphere((-2.0, -16.0, 24), 3.5, (0.9, 0.9, 1.0), 0.8, 0.0),
+            scenes.Sphere((6.0, -17.0, 22), 2.5, (0.8, 0.3, 0.3), 0.0, 0.0)]
+    objs += scenes.planes(scenes.stone_small_texture(True))
+    objs.append(scenes.TriangleMesh.from_triangles(scenes.bunny_tris() * 0.6 + np.tile([4.0, -2.0, 10.0], 3),
+                                                   (1.0, 1.0, 1.0), 0.8, 0.5))
+    objs.append(scenes.TriangleMesh.from_triangles(scenes.pyramid_tris(0.6, (-6.0, -13.0, 38.0)), (0.6, 0.7, 0.9), 0.0, 0.0))
+    objs.append(scenes.vase_bezier())
+    W, H, spp = 128, 96, 2
+    o = BackendScene(orc, objs)
+    want = o.trace_grid(scenes.cam_dof(), W, H, spp, 5, seed=3)
+    o.close()
+    sc = cg.Scene(objs)
+    got = sc.trace_grid_host(W, H, spp, scenes.cam_dof(), 5, 3)
+    hp = sc.trace_grid_hitpoints(W, H, spp, scenes.cam_dof(), 5, 3)
+    sc.close()
+    ref32 = to_acc32(want["acc_sum"], spp)
+    ok = np.abs(got["rgb"] - ref32).max(axis=-1) < 1e-4
+    print("everything: pixels within 1e-4: %.5f, rays %d vs %d, hitpoints %d" % (ok.mean(), got["nrays"], want["nrays"], hp["count"]))
+    assert ok.mean() >= 0.995
+    assert abs(got["nrays"] - want["nrays"]) <= 0.005 * want["nrays"]
+    assert hp["count"] == got["nhp"]
