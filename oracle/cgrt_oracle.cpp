@@ -507,14 +507,17 @@ struct RayCtx {
     uint64_t seed, pixel, sample;
 };
 
+// `seq`: when non-null (photon pass) Bezier draws continue on that sequential stream, as the reference's rand()
+// does; otherwise (eye pass) they come from the ray's own path-keyed stream.
 static bool obj_intersect(const Scene &sc, int i, const V3 &o, const V3 &d, double &len, V3 &n, const RayCtx &rc,
-                          uint32_t path, Sink &sink) {
+                          uint32_t path, Sink &sink, Rng *seq = nullptr) {
     const Obj &ob = *sc.objs[i];
     switch (ob.kind) {
         case SPHERE: return sphere_intersect(ob, o, d, len, n);
         case PLANE: return plane_intersect(sc, ob, o, d, len, n, sink.stats);
         case MESH: return mesh_intersect(ob, o, d, len, n, sink.stats);
         case BEZIER: {
+            if (seq) return bezier_intersect(ob, o, d, len, n, *seq);
             Rng r{cgrt_key(rc.seed, rc.pixel, rc.sample, ((uint64_t)path << 16) | (uint64_t)(i + 1)), 0};
             return bezier_intersect(ob, o, d, len, n, r);
         }
@@ -583,6 +586,158 @@ static void trace(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int dep
         V3 fa = mul(f, adj);
         trace(sc, P + normalvec * EPS, refl_dir, fa * Re, depth_left - 1, path * 2, rc, sink);
         trace(sc, P - normalvec * EPS, refr_dir, fa * (1 - Re), depth_left - 1, path * 2 + 1, rc, sink);
+    }
+}
+
+// ---------------------------------------------------------------- photon pass, main.cpp:101-128,158-165,223-258
+// hitpoints.h:6-20 / hash.h:20-70.  Buckets keep insertion order; a photon event visits the 27 cells around it and,
+// for each, EVERY hitpoint of the bucket that cell hashes to (hash.h:32-34), so a hitpoint is updated once per
+// neighbouring cell whose hash equals its bucket -- normally once, twice on a hash collision inside the 3x3x3 block.
+struct Hitpt {
+    V3 f, pos, normal, flux;
+    double r2;
+    int n, h, w;
+};
+struct HashGrid {
+    int hashsize, ncell;
+    double celllength;
+    std::vector<std::vector<Hitpt> > buckets;
+    HashGrid(int hs, double cl) : hashsize(hs) {  // hash.h:22-30
+        ncell = (int)std::ceil(70.0 / cl);
+        celllength = 70.0 / ncell;
+        buckets.assign((size_t)hs, std::vector<Hitpt>());
+    }
+    unsigned hash(int ix, int iy, int iz) const {  // hash.h:35-37 (wrapping int products)
+        return (((unsigned)ix * 73856093u) ^ ((unsigned)iy * 19349663u) ^ ((unsigned)iz * 83492791u)) % (unsigned)hashsize;
+    }
+    void coord(double x, double y, double z, int &ix, int &iy, int &iz) const {  // hash.h:38-42
+        ix = (int)std::floor((x - (-35.0)) / celllength);
+        iy = (int)std::floor((y - (-35.0)) / celllength);
+        iz = (int)std::floor((z - (-15.0)) / celllength);
+    }
+    void insert(const Hitpt &hp) {  // hash.h:43-54
+        int ix, iy, iz;
+        coord(hp.pos.x, hp.pos.y, hp.pos.z, ix, iy, iz);
+        buckets[hash(ix, iy, iz)].push_back(hp);
+    }
+};
+static const double PI_REF = 3.14159265358979;  // main.cpp:26
+
+// sampling.h:11-29 on the photon's sequential stream
+static V3 sample_sphere(Rng &r) {
+    while (true) {
+        double x = r.u01() * 2.0 - 1, y = r.u01() * 2.0 - 1, z = r.u01() * 2.0 - 1;
+        if (x * x + y * y + z * z <= 1) return normalized(V3(x, y, z));
+    }
+}
+static V3 sample_halfsphere(Rng &r, const V3 &dir) {
+    while (true) {
+        V3 s = sample_sphere(r);
+        if (dot(s, dir) > 0) return s;
+    }
+}
+
+// eye-pass trace that stores Hitpoints (main.cpp:85-100) instead of accumulating them
+static void trace_store(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int depth_left, uint32_t path,
+                        const RayCtx &rc, HashGrid &ht, int lw, int lh, double r0, Sink &sink) {
+    if (depth_left <= 0) return;
+    double len = 0;
+    int id = -1;
+    V3 normalvec, temp;
+    double nearest = INF;
+    for (int i = 0; i < (int)sc.objs.size(); i++)
+        if (obj_intersect(sc, i, org, dir, len, temp, rc, path, sink) && len < nearest) { id = i; nearest = len; normalvec = temp; }
+    if (id == -1) return;
+    const Obj &obj = *sc.objs[id];
+    V3 P = org + dir * nearest;
+    bool into = true;
+    V3 n_old = normalvec;
+    if (dot(normalvec, dir) > 0) { normalvec = -normalvec; into = false; }
+    V3 f = obj.color;
+    if (obj.kind == PLANE && obj.tex >= 0) { V3 c; if (sc.textures[obj.tex]->color(P, c)) f = c; }
+    if (obj.refl < EPS && obj.transp < EPS) {
+        Hitpt hp;
+        hp.f = mul(f, adj); hp.pos = P; hp.normal = normalvec; hp.w = lw; hp.h = lh; hp.flux = V3(); hp.r2 = r0 * r0; hp.n = 0;
+        ht.insert(hp);
+    } else if (obj.transp < EPS) {
+        V3 newdir = dir - normalvec * 2.0 * dot(normalvec, dir);
+        trace_store(sc, P + normalvec * EPS, newdir, mul(f, adj) * obj.refl, depth_left - 1, path * 2, rc, ht, lw, lh, r0, sink);
+    } else {
+        double nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
+        V3 refl_dir = dir - n_old * 2.0 * dot(n_old, dir);
+        if ((cos2t = 1 - nnt * nnt * (1 - ddn * ddn)) < 0) {
+            trace_store(sc, P + normalvec * EPS, refl_dir, adj, depth_left - 1, path * 2, rc, ht, lw, lh, r0, sink);
+            return;
+        }
+        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + std::sqrt(cos2t))));
+        double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
+        double Re = R0 + (1 - R0) * c * c * c * c * c;
+        V3 fa = mul(f, adj);
+        trace_store(sc, P + normalvec * EPS, refl_dir, fa * Re, depth_left - 1, path * 2, rc, ht, lw, lh, r0, sink);
+        trace_store(sc, P - normalvec * EPS, refr_dir, fa * (1 - Re), depth_left - 1, path * 2 + 1, rc, ht, lw, lh, r0, sink);
+    }
+}
+
+// trace(flag=false), main.cpp:42-81,101-128,129-165
+static void trace_photon(const Scene &sc, const V3 &org, const V3 &dir, V3 flux, V3 adj, int depth_left, Rng &rng,
+                         HashGrid &ht, double alpha, Sink &sink) {
+    if (depth_left <= 0) return;
+    static const RayCtx none{0, 0, 0};
+    double len = 0;
+    int id = -1;
+    V3 normalvec, temp;
+    double nearest = INF;
+    for (int i = 0; i < (int)sc.objs.size(); i++)
+        if (obj_intersect(sc, i, org, dir, len, temp, none, 0, sink, &rng) && len < nearest) { id = i; nearest = len; normalvec = temp; }
+    if (id == -1) return;
+    const Obj &obj = *sc.objs[id];
+    V3 P = org + dir * nearest;
+    bool into = true;
+    V3 n_old = normalvec;
+    if (dot(normalvec, dir) > 0) { normalvec = -normalvec; into = false; }
+    V3 f = obj.color;
+    if (obj.kind == PLANE && obj.tex >= 0) { V3 c; if (sc.textures[obj.tex]->color(P, c)) f = c; }
+    double p = max3(f.x, f.y, f.z);  // main.cpp:79
+    if (obj.refl < EPS && obj.transp < EPS) {
+        int ix, iy, iz;
+        ht.coord(P.x, P.y, P.z, ix, iy, iz);
+        ix -= 1; iy -= 1; iz -= 1;
+        for (int dx = 0; dx < 3; dx++)
+            for (int dy = 0; dy < 3; dy++)
+                for (int dz = 0; dz < 3; dz++) {
+                    std::vector<Hitpt> &bk = ht.buckets[ht.hash(ix + dx, iy + dy, iz + dz)];
+                    for (size_t i = 0; i < bk.size(); i++) {
+                        Hitpt &hp = bk[i];
+                        V3 dd = hp.pos - P;
+                        if ((dot(hp.normal, normalvec) > EPS) && (dot(dd, dd) <= hp.r2)) {  // main.cpp:116
+                            double g = (hp.n * alpha + alpha) / (hp.n * alpha + 1.0);    // main.cpp:119
+                            hp.r2 *= g;
+                            hp.n++;
+                            hp.flux = (hp.flux + mul(hp.f, flux) * (1.0 / PI_REF)) * g;  // main.cpp:122
+                        }
+                    }
+                }
+        V3 newdir = sample_halfsphere(rng, normalvec);                                   // main.cpp:126
+        trace_photon(sc, P, newdir, mul(f, flux) * (1.0 / p), adj, depth_left - 1, rng, ht, alpha, sink);
+    } else if (obj.transp < EPS) {
+        V3 newdir = dir - normalvec * 2.0 * dot(normalvec, dir);
+        trace_photon(sc, P + normalvec * EPS, newdir, mul(f, flux) * obj.refl, mul(f, adj) * obj.refl, depth_left - 1, rng, ht,
+                     alpha, sink);
+    } else {
+        double nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
+        V3 refl_dir = dir - n_old * 2.0 * dot(n_old, dir);
+        if ((cos2t = 1 - nnt * nnt * (1 - ddn * ddn)) < 0) {
+            trace_photon(sc, P + normalvec * EPS, refl_dir, flux, adj, depth_left - 1, rng, ht, alpha, sink);
+            return;
+        }
+        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + std::sqrt(cos2t))));
+        double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
+        double Re = R0 + (1 - R0) * c * c * c * c * c;
+        V3 fa = mul(f, adj);
+        if (rng.u01() < 0.5)  // main.cpp:160-164: Russian roulette; the photon's flux is not attenuated by glass
+            trace_photon(sc, P + normalvec * EPS, refl_dir, flux, fa * Re * 0.3, depth_left - 1, rng, ht, alpha, sink);
+        else
+            trace_photon(sc, P - normalvec * EPS, refr_dir, flux, fa * (1 - Re * 0.3), depth_left - 1, rng, ht, alpha, sink);
     }
 }
 
@@ -897,6 +1052,69 @@ double orc_trace_grid(void *sp, const orc_camera *cam, const orc_grid *g, int ha
     if (nrays) *nrays = total_rays;
     if (hp_count) *hp_count = total_hp;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// eye pass + serial photon pass + final gather; same signature and record layout as ref_ppm (cgrt_testapi.h)
+int64_t orc_ppm(void *sp, const orc_camera *cam, const orc_grid *g, const orc_photons *ph, double *hp_out,
+                uint64_t hp_cap, double *image_out) {
+    Scene *s = (Scene *)sp;
+    const int W = g->W, H = g->H;
+    V3 camorg = v3(cam->cam);
+    const double r0 = 200.0 / 768;  // main.cpp:84,183 with the reference's compile-time height
+    HashGrid ht(ph->hashsize, r0);
+    Sink sink;
+    double dummy_acc[3] = {0, 0, 0};
+    uint32_t dummy_hit = 0;
+    sink.acc = dummy_acc;
+    sink.nhit = &dummy_hit;
+    for (int h = g->row0; h < g->row0 + g->nrows; h++)
+        for (int w = 0; w < W; w++) {
+            double x = (2.0 * ((double)w / W) - 1) * cam->half_width;
+            double y = (2.0 * ((double)h / H) - 1) * cam->half_width * H / W;
+            V3 dir = normalized(V3(x, y, 0) - camorg);
+            V3 pof = dir * ((cam->focus_plane - camorg.z) / dir.z) + camorg;
+            for (int j = g->sample0; j < g->sample0 + g->spp; j++) {
+                RayCtx rc{g->seed, (uint64_t)h * (uint64_t)W + (uint64_t)w, (uint64_t)j};
+                const int lw = w + W * (j - g->sample0), lh = h - g->row0;
+                if (cam->lens_radius > 0) {
+                    Rng r{cgrt_key(rc.seed, rc.pixel, rc.sample, 0), 0};
+                    V3 neworg = camorg + lens_sample(r, cam->lens_radius);
+                    V3 newdir = normalized(pof - neworg);
+                    trace_store(*s, neworg, newdir, V3(1, 1, 1), g->depth, 1, rc, ht, lw, lh, r0, sink);
+                } else {
+                    trace_store(*s, camorg, dir, V3(1, 1, 1), g->depth, 1, rc, ht, lw, lh, r0, sink);
+                }
+            }
+        }
+    V3 light = v3(ph->light);
+    for (int64_t i = 0; i < ph->nphotons; i++) {  // main.cpp:231-248, serial
+        Rng rng{cgrt_key(ph->seed, (uint64_t)i, 0, CGRT_PURPOSE_PHOTON), 0};
+        double a = rng.u01() * (2 * ph->jitter) - ph->jitter;
+        double b = rng.u01() * (2 * ph->jitter) - ph->jitter;
+        V3 dir = sample_sphere(rng);
+        trace_photon(*s, light + V3(a, 0, b), dir, V3(ph->power, ph->power, ph->power) * (PI_REF * 4.0), V3(1, 1, 1), g->depth, rng,
+                     ht, ph->alpha, sink);
+    }
+    int64_t k = 0;
+    for (size_t b = 0; b < ht.buckets.size(); b++)
+        for (size_t i = 0; i < ht.buckets[b].size(); i++) {
+            const Hitpt &q = ht.buckets[b][i];
+            const int col = q.w % W, smp = q.w / W;
+            const size_t pix = (size_t)q.h * W + col;
+            if (image_out) {
+                V3 c = q.flux * (1.0 / (PI_REF * q.r2 * (double)ph->nphotons * g->spp));
+                image_out[3 * pix] += c.x; image_out[3 * pix + 1] += c.y; image_out[3 * pix + 2] += c.z;
+            }
+            if (hp_out && (uint64_t)k < hp_cap) {
+                double *o = hp_out + 16 * k;
+                o[0] = (double)pix; o[1] = (double)smp;
+                o[2] = q.f.x; o[3] = q.f.y; o[4] = q.f.z; o[5] = q.pos.x; o[6] = q.pos.y; o[7] = q.pos.z;
+                o[8] = q.normal.x; o[9] = q.normal.y; o[10] = q.normal.z;
+                o[11] = q.flux.x; o[12] = q.flux.y; o[13] = q.flux.z; o[14] = q.r2; o[15] = (double)q.n;
+            }
+            k++;
+        }
+    return k;
 }
 
 }  // extern "C"

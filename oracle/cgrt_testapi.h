@@ -29,4 +29,21 @@ typedef struct {
  *   hp    [cap*9]     double : optional hitpoint stream f(3) pos(3) normal(3), emission order
  *   hp_pix[cap]       int64  : (sample << 32) | local pixel index
  */
+
+/* Photon pass (main.cpp:223-258).  Deterministic SERIAL semantics: photons are
+ * traced one after another in index order on one thread, photon i drawing from the keyed stream
+ * cgrt_key(seed, i, 0, CGRT_PURPOSE_PHOTON) in the reference's own call order. */
+#define CGRT_PURPOSE_PHOTON 0x70686f74ULL
+typedef struct {
+    double light[3];   /* main.cpp:180  lightorg = (0,19.999,20)                                   */
+    double jitter;     /* main.cpp:240-241  a,b = u*4-2: half extent 2.0 of the square emitter      */
+    double power;      /* main.cpp:246  Vec3(700,700,700) * (PI*4.0): the 700                       */
+    double alpha;      /* main.cpp:36   0.7                                                         */
+    int64_t nphotons;  /* photons traced in total (reference: num_photon * num_threads, main.cpp:223-224) */
+    int32_t hashsize;  /* main.cpp:184  1000001                                                     */
+    int32_t pad_;
+    uint64_t seed;
+} orc_photons;
+/* per-hitpoint output record of *_ppm: 16 doubles
+ *   [0] local pixel index  [1] sample index  [2..4] f  [5..7] pos  [8..10] normal  [11..13] flux  [14] r2  [15] n */
 #endif

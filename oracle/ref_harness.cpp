@@ -333,4 +333,75 @@ double ref_trace_grid(void *sp, const orc_camera *cam, const orc_grid *g, int ha
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// ---- eye pass + photon pass + final gather: render() (main.cpp:169-266) with its constants as arguments -------
+// The eye pass fills the reference's own Hashtable (real hash size, so bucket collisions behave as in the
+// reference); the photon loop (main.cpp:231-248) runs SERIALLY in photon-index order -- the reference's OpenMP
+// region is racy and time-seeded, this is its deterministic single-thread meaning -- with rand() redirected to
+// the photon's keyed stream; trace(flag=false) and the samplers are the reference's own code.
+// hp_out: 16 doubles per hitpoint (cgrt_testapi.h) in bucket order; image: nrows*W*3, main.cpp:252-258.
+int64_t ref_ppm(void *sp, const orc_camera *cam, const orc_grid *g, const orc_photons *ph, double *hp_out,
+                uint64_t hp_cap, double *image_out) {
+    RefScene *s = (RefScene *)sp;
+    std::vector<Object *> objs = s->objs;
+    const int W = g->W, H = g->H;
+    Vec3 camorg = v3(cam->cam);
+    double r = 200.0 / height;  // main.cpp:183 (the global `height` = 768 that trace() also uses, main.cpp:84)
+    Hashtable htable = Hashtable(ph->hashsize, r);
+    const int start_depth = MAX_DEPTH - g->depth;
+    for (int h = g->row0; h < g->row0 + g->nrows; h++) {
+        for (int w = 0; w < W; w++) {
+            double x = (2.0 * ((double)w / W) - 1) * cam->half_width;
+            double y = (2.0 * ((double)h / H) - 1) * cam->half_width * H / W;
+            Vec3 dir = (Vec3(x, y, 0) - camorg).normalize();
+            Vec3 point_on_focus = dir * ((cam->focus_plane - camorg.z) / dir.z) + camorg;
+            for (int j = g->sample0; j < g->sample0 + g->spp; j++) {
+                int lw = w + W * (j - g->sample0), lh = h - g->row0;
+                g_rng_key = cgrt_key(g->seed, (uint64_t)h * (uint64_t)W + (uint64_t)w, (uint64_t)j, 0);
+                g_rng_ctr = 0;
+                if (cam->lens_radius > 0) {
+                    Vec3 neworg = camorg + uniform_sampling_circle(cam->lens_radius);
+                    Vec3 newdir = (point_on_focus - neworg).normalize();
+                    trace(neworg, newdir, objs, Vec3(), Vec3(1, 1, 1), true, start_depth, htable, lw, lh);
+                } else {
+                    trace(camorg, dir, objs, Vec3(), Vec3(1, 1, 1), true, start_depth, htable, lw, lh);
+                }
+            }
+        }
+    }
+    Vec3 lightorg = v3(ph->light);
+    for (int64_t i = 0; i < ph->nphotons; i++) {  // main.cpp:231-248
+        g_rng_key = cgrt_key(ph->seed, (uint64_t)i, 0, CGRT_PURPOSE_PHOTON);
+        g_rng_ctr = 0;
+        double a = uniform_sampling_zeroone() * (2 * ph->jitter) - ph->jitter;
+        double b = uniform_sampling_zeroone() * (2 * ph->jitter) - ph->jitter;
+        Vec3 disturbance = Vec3(a, 0, b);
+        Vec3 dir = uniform_sampling_sphere();
+        trace(lightorg + disturbance, dir, objs, Vec3(ph->power, ph->power, ph->power) * (PI * 4.0), Vec3(1, 1, 1), false,
+              start_depth, htable, 0, 0);
+    }
+    int64_t k = 0;
+    for (size_t bkt = 0; bkt < htable.hashtable.size(); bkt++) {
+        for (size_t i = 0; i < htable.hashtable[bkt].size(); i++) {
+            const Hitpoint &q = htable.hashtable[bkt][i];
+            const int col = q.w % W, smp = q.w / W;
+            const size_t pix = (size_t)q.h * W + col;
+            if (image_out) {  // main.cpp:256
+                Vec3 c = q.flux * (1.0 / (PI * q.r2 * (double)ph->nphotons * g->spp));
+                image_out[3 * pix] += c.x; image_out[3 * pix + 1] += c.y; image_out[3 * pix + 2] += c.z;
+            }
+            if (hp_out && (uint64_t)k < hp_cap) {
+                double *o = hp_out + 16 * k;
+                o[0] = (double)pix; o[1] = (double)smp;
+                o[2] = q.f.x; o[3] = q.f.y; o[4] = q.f.z;
+                o[5] = q.pos.x; o[6] = q.pos.y; o[7] = q.pos.z;
+                o[8] = q.normal.x; o[9] = q.normal.y; o[10] = q.normal.z;
+                o[11] = q.flux.x; o[12] = q.flux.y; o[13] = q.flux.z;
+                o[14] = q.r2; o[15] = (double)q.n;
+            }
+            k++;
+        }
+    }
+    return k;
+}
+
 }  // extern "C"

@@ -25,6 +25,11 @@ class OrcGrid(C.Structure):
                 ("seed", C.c_uint64)]
 
 
+class OrcPhotons(C.Structure):
+    _fields_ = [("light", C.c_double * 3), ("jitter", C.c_double), ("power", C.c_double), ("alpha", C.c_double),
+                ("nphotons", C.c_int64), ("hashsize", C.c_int32), ("pad_", C.c_int32), ("seed", C.c_uint64)]
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -81,6 +86,9 @@ class Backend:
         f("tree_dump").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         f("plane_bump_ntris").argtypes = [C.c_void_p, C.c_int]
         f("plane_bump_tris").argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        f("ppm").restype = C.c_int64
+        f("ppm").argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.POINTER(OrcGrid), C.POINTER(OrcPhotons), C.c_void_p,
+                             C.c_uint64, C.c_void_p]
         if prefix == "orc":
             L.orc_set_threads.argtypes = [C.c_int]
         self.f = f
@@ -167,6 +175,21 @@ class BackendScene:
             out["hp_pix"] = (hp_pix[:n] & 0xFFFFFFFF).astype(np.int64)
             out["hp_smp"] = (hp_pix[:n] >> 32).astype(np.int64)
         return out
+
+    def ppm(self, cam, W, H, spp=1, depth=5, seed=12345, nphotons=10000, photon_seed=777, hashsize=1000001,
+            light=(0.0, 19.999, 20.0), jitter=2.0, power=700.0, alpha=0.7):
+        """Eye pass + serial photon pass + final gather (main.cpp:169-258).  Returns dict(hp [n,16] sorted
+        canonically by (pixel, sample, pos), image [H,W,3] float64)."""
+        c = OrcCamera(_d3(cam.cam), cam.half_width, cam.focus_plane, cam.lens_radius)
+        g = OrcGrid(W, H, 0, H, spp, 0, depth, 0, seed)
+        ph = OrcPhotons(_d3(light), jitter, power, alpha, nphotons, hashsize, 0, photon_seed)
+        cap = W * H * spp * 16
+        hp = np.zeros((cap, 16), np.float64)
+        img = np.zeros((H, W, 3), np.float64)
+        n = self.be.f("ppm")(self.h, C.byref(c), C.byref(g), C.byref(ph), hp.ctypes.data, cap, img.ctypes.data)
+        hp = hp[:n]
+        order = np.lexsort([hp[:, 7], hp[:, 6], hp[:, 5], hp[:, 1], hp[:, 0]])
+        return dict(hp=hp[order], image=img, n=int(n))
 
     def intersect_batch(self, obj, org, dirs, keys=None):
         org = np.ascontiguousarray(org, np.float64)

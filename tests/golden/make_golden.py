@@ -46,6 +46,18 @@ def trace_cases():
     ]
 
 
+def photon_cases():
+    S = scenes
+    bump = lambda: S.planes(S.stone_small_texture(True)) + [S.Sphere((5, -12, 30), 5, (1, 1, 1), 0.8, 0.5)]
+    return [
+        # name, objs, camera, W, H, spp, photons
+        ("c2_48x36", S.scene_c2, S.cam_pinhole, 48, 36, 1, 20000),
+        ("c2_dof_32x24", S.scene_c2, S.cam_dof, 32, 24, 2, 20000),
+        ("bunny_40", lambda: S.scene_c3(True), S.cam_pinhole, 40, 40, 1, 15000),
+        ("bump_40x30", bump, S.cam_pinhole, 40, 30, 1, 15000),
+    ]
+
+
 def fingerprint(nodes, leaf):
     sizes = nodes[:, 2]
     leaves = sizes[sizes < 10]
@@ -204,6 +216,12 @@ def main():
     r6 = s6.trace_grid(scenes.cam_pinhole(), 48, 48, 1, 5, seed=12345)
     np.savez_compressed(os.path.join(HERE, "trace_bezier_vase_48_statistical.npz"), acc_sum=r6["acc_sum"],
                         nhit=r6["nhit"], nrays=np.int64(r6["nrays"]))
+    # ---- photon pass (row f1), serial keyed semantics: per-hitpoint (f,pos,normal,flux,r2,n) and the gathered image ----
+    for name, mk, cam, W, H, spp, nph in photon_cases():
+        s7 = BackendScene(ref, mk())
+        r7 = s7.ppm(cam(), W, H, spp, 5, nphotons=nph)
+        np.savez_compressed(os.path.join(HERE, "ppm_%s.npz" % name), hp=r7["hp"], image=r7["image"])
+        print("ppm", name, r7["n"], float(r7["hp"][:, 15].max()))
     # ---- loaders: one process per file ----
     write_test_meshes()
     for name in LOADER_CASES:

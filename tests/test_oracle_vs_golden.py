@@ -146,3 +146,18 @@ def test_depth_and_sample_ranges(orc):
     assert np.array_equal(top["acc_sum"], full["acc_sum"][8:])
     d1 = s.trace_grid(cam, 40, 24, spp=1, depth=1)
     assert d1["nrays"] == 40 * 24
+
+
+@pytest.mark.parametrize("case", make_golden.photon_cases(), ids=[c[0] for c in make_golden.photon_cases()])
+def test_photon_pass_matches_reference_golden(orc, case):
+    """Row f1: eye pass + SERIAL photon pass + final gather.  The reference's own trace(flag=false),
+    samplers and hash grid, run on one thread with rand() on the photons' keyed streams, are deterministic; the
+    oracle reproduces every hitpoint's (f, pos, normal, flux, r2, n) and the gathered image bit for bit."""
+    name, mk, cam, W, H, spp, nph = case
+    g = np.load(os.path.join(GOLD, "ppm_%s.npz" % name))
+    s = BackendScene(orc, mk())
+    r = s.ppm(cam(), W, H, spp, 5, nphotons=nph)
+    assert r["hp"].shape == g["hp"].shape
+    assert np.array_equal(r["hp"], g["hp"])
+    assert np.array_equal(r["image"], g["image"])
+    assert g["hp"][:, 15].max() > 10  # photons really were gathered
