@@ -32,6 +32,11 @@ class Grid(C.Structure):
                 ("max_depth", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64)]
 
 
+class Photons(C.Structure):
+    _fields_ = [("light", C.c_double * 3), ("jitter", C.c_double), ("power", C.c_double), ("alpha", C.c_double),
+                ("nphotons", C.c_int64), ("hashsize", C.c_int32), ("batch", C.c_int32), ("seed", C.c_uint64)]
+
+
 class SceneStats(C.Structure):
     _fields_ = [("n_objects", C.c_int32), ("n_spheres", C.c_int32), ("n_planes", C.c_int32),
                 ("n_meshes", C.c_int32), ("n_beziers", C.c_int32), ("n_textures", C.c_int32),
@@ -66,6 +71,10 @@ SIGNATURES = {
                                        C.c_void_p]),
     "cgrt_trace_grid_hitpoints": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_uint64,
                                             C.POINTER(C.c_uint64)]),
+    "cgrt_ppm_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.POINTER(Photons), C.c_void_p,
+                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cgrt_photon_events": (C.c_int, [C.c_void_p, C.POINTER(Photons), C.c_int, C.c_int64, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
     "cgrt_lens_samples": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "cgrt_intersect_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

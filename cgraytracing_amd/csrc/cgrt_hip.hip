@@ -804,6 +804,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
 
     double acc_r = 0, acc_g = 0, acc_b = 0;
     uint32_t my_hits = 0, my_rays = 0, my_nodes = 0, my_tris = 0, wave_iters = 0;
+    uint32_t hp_seq = 0;  // HPS: index of the next Hitpoint within the current sample's ray tree (emission order)
 
     Pending deep[2];   // third stack level (scratch; indexed dynamically so that it stays out of registers)
     Pending sib;       // refracted sibling of a leaf-level glass hit (registers)
@@ -841,6 +842,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
                 depth_left = g.max_depth;
                 path = 1;
                 s++;
+                hp_seq = 0;
                 have = true;
             }
         }
@@ -884,10 +886,12 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
                             q[0] = hf.x; q[1] = hf.y; q[2] = hf.z;
                             q[3] = P.x; q[4] = P.y; q[5] = P.z;
                             q[6] = n.x; q[7] = n.y; q[8] = n.z;
-                            // label: local pixel index and sample index, like Hitpoint::w/h (main.cpp:91-92)
-                            q[9] = (double)((unsigned long long)(s - 1) * (unsigned long long)g.W * g.rows +
-                                            (unsigned long long)j * g.W + w);
+                            // label: (sample, local pixel) like Hitpoint::w/h (main.cpp:91-92), times 16, plus the
+                            // hitpoint's position in the sample's emission order (<= 16 per tree)
+                            q[9] = (double)((((unsigned long long)(s - 1) * (unsigned long long)g.W * g.rows +
+                                              (unsigned long long)j * g.W + w) << 4) | (unsigned long long)hp_seq);
                         }
+                        hp_seq++;
                     }
                 } else if (depth_left > 1) {
                     if (transp < kEps) {
@@ -1491,3 +1495,5 @@ int cgrt_lens_samples(uint64_t seed, const int64_t *pixel, const int32_t *sample
 }
 
 }  // extern "C"
+
+#include "cgrt_photon.inc"

@@ -59,25 +59,21 @@ CGRT_HD double div_rand_max(uint32_t r) {
 }
 
 struct Stream {
-    uint64_t state;   // key + j*G
-    uint32_t spare;   // second draw of the current z_j
-    bool has_spare;
-    CGRT_HD explicit Stream(uint64_t key) : state(key), spare(0), has_spare(false) {}
+    // Stateless form: draw n is a pure function of (key, n), so there is no carried "second half" flag (a carried
+    // bool was lost across iterations of a divergent device loop); odd draws recompute the finaliser.
+    uint64_t key;
+    uint32_t n;  // draws consumed
+    CGRT_HD explicit Stream(uint64_t k) : key(k), n(0) {}
     CGRT_HD uint32_t next31() {
-        if (has_spare) {
-            has_spare = false;
-            return spare;
-        }
-        state += kGolden;
-        const uint64_t z = fin64(state);
-        spare = (uint32_t)((z >> 2) & 0x7fffffffu);
-        has_spare = true;
-        return (uint32_t)(z >> 33);
+        const uint64_t z = fin64(key + (uint64_t)(n / 2u + 1u) * kGolden);
+        const uint32_t r = (n & 1u) ? (uint32_t)((z >> 2) & 0x7fffffffu) : (uint32_t)(z >> 33);
+        n++;
+        return r;
     }
     // two consecutive draws at an even position of the stream (the lens sampler's x, y): one finaliser
     CGRT_HD void pair(double &a, double &b) {
-        state += kGolden;
-        const uint64_t z = fin64(state);
+        const uint64_t z = fin64(key + (uint64_t)(n / 2u + 1u) * kGolden);
+        n += 2u;
         a = div_rand_max((uint32_t)(z >> 33));
         b = div_rand_max((uint32_t)((z >> 2) & 0x7fffffffu));
     }

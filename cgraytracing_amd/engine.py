@@ -158,7 +158,38 @@ class Scene:
         check(self._L.cgrt_trace_grid_hitpoints(self._h, C.byref(cc), C.byref(g), rec.ctypes.data, cap, C.byref(n)))
         m = min(int(n.value), cap)
         lab = rec[:m, 9].astype(np.int64)
-        return dict(hp=rec[:m, :9].copy(), pix=lab % (rows * width), smp=lab // (rows * width), count=int(n.value))
+        seq, lab = lab & 15, lab >> 4
+        return dict(hp=rec[:m, :9].copy(), pix=lab % (rows * width), smp=lab // (rows * width), seq=seq,
+                    count=int(n.value))
+
+    def ppm_render(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, nphotons=100000, photon_seed=777,
+                   hashsize=1000001, light=(0.0, 19.999, 20.0), jitter=2.0, power=700.0, alpha=0.7, batch=0,
+                   want_hitpoints=False):
+        """Eye pass + photon pass + final gather (render(), main.cpp:169-258, serial photon semantics).
+        Returns dict(image [H,W,3] float64, and with want_hitpoints: hp [n,16])."""
+        cc, g = self._structs(camera, width, height, height, spp, max_depth, seed, 0, None, 0, None, 0)
+        ph = _capi.Photons(_d3(light), jitter, power, alpha, nphotons, hashsize, batch, photon_seed)
+        img = np.zeros((height, width, 3), np.float64)
+        n = C.c_uint64(0)
+        cap = height * width * spp * 16 if want_hitpoints else 0
+        hp = np.zeros((max(cap, 1), 16), np.float64)
+        check(self._L.cgrt_ppm_render(self._h, C.byref(cc), C.byref(g), C.byref(ph), img.ctypes.data,
+                                      hp.ctypes.data if want_hitpoints else None, cap, C.byref(n)))
+        out = dict(image=img, count=int(n.value))
+        if want_hitpoints:
+            out["hp"] = hp[: int(n.value)]
+        return out
+
+    def photon_events(self, first, count, max_depth=5, photon_seed=777, light=(0.0, 19.999, 20.0), jitter=2.0,
+                      power=700.0):
+        """Verification probe: diffuse hits of photons [first, first+count): [n,10] = photon, P, n, flux in serial
+        order (slot order)."""
+        ph = _capi.Photons(_d3(light), jitter, power, 0.7, count, 1000001, 0, photon_seed)
+        ev = np.zeros((count * 8, 9), np.float64)
+        va = np.zeros(count * 8, np.uint8)
+        check(self._L.cgrt_photon_events(self._h, C.byref(ph), max_depth, first, count, ev.ctypes.data, va.ctypes.data))
+        idx = np.nonzero(va)[0]
+        return np.concatenate([(first + idx // 8)[:, None].astype(np.float64), ev[idx]], axis=1)
 
     def intersect_rays(self, obj, org, dirs, keys=None):
         org = np.ascontiguousarray(org, np.float64)

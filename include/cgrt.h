@@ -159,11 +159,40 @@ int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt
 
 /* The Hitpoint stream the reference would have inserted into its hash table (main.cpp:87-98, hash.h:43-54), for
  * the same grid: up to `cap` records of 10 doubles {f(3) = surface colour * adj, pos(3), normal(3), label} are written
- * to the HOST buffer hp10 in no particular order; label = sample_index * (rows*width) + local pixel index.  *count
+ * to the HOST buffer hp10 in no particular order; label = ((sample_index * (rows*width) + local pixel index) << 4) |
+ * position of the hitpoint in that sample's emission order.  *count
  * receives the number of hitpoints produced (if > cap the excess was dropped).  This is the hand-off a photon pass
  * would consume and what parity tests compare with the reference's own records. */
 int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, double *hp10,
                               uint64_t cap, uint64_t *count);
+
+/* ---- row f1 of SURVEY.md section 8: the photon pass and final gather, render() main.cpp:223-258 ----------------
+ * Constants of the reference as fields.  The reference races eight OpenMP threads over time-seeded rand(); what is
+ * implemented is its SERIAL meaning (photons in index order, photon i on the keyed stream (seed, i)), which the
+ * compiled reference reproduces on one thread and which golden vectors pin bit for bit. */
+typedef struct cgrt_photons {
+    double light[3];   /* lightorg, main.cpp:180: (0, 19.999, 20)                                                  */
+    double jitter;     /* main.cpp:240-241: emitter half extent 2.0 (a, b = u*4-2)                                  */
+    double power;      /* main.cpp:246: 700 (flux = power * 4*PI per channel)                                      */
+    double alpha;      /* main.cpp:36: 0.7                                                                         */
+    int64_t nphotons;  /* photons in total (reference: num_photon * num_threads = 20 480 000, main.cpp:223-224)     */
+    int32_t hashsize;  /* main.cpp:184: 1000001 (bucket collisions are part of the semantics, hash.h:32-37)         */
+    int32_t batch;     /* photons traced per batch (0 = default 262144); does not change the result                */
+    uint64_t seed;
+} cgrt_photons;
+
+/* Eye pass + photon pass + final gather for grid (contiguous rows only; Bezier objects not yet supported).
+ * image: HOST buffer rows*width*3 doubles, image[h][w] = sum over the pixel's hitpoints of flux / (PI * r2 * nphotons * spp)
+ * (main.cpp:256).  hp16 (optional, HOST): per hitpoint 16 doubles {pixel*spp+sample, emission index, f(3), pos(3),
+ * normal(3), flux(3), r2, n} in the reference's table order. */
+int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, const cgrt_photons *ph,
+                    double *image, double *hp16, uint64_t hp_cap, uint64_t *hp_count);
+
+/* Verification probe for photon paths: the diffuse hits (the events the serial loop of main.cpp:103-125 processes) of
+ * photons [first, first+count): events9 = count*8 slots of 9 doubles {P(3), n(3), flux(3)}, slot = (photon-first)*8 +
+ * path segment; valid = one byte per slot.  HOST buffers. */
+int cgrt_photon_events(const cgrt_scene *s, const cgrt_photons *ph, int max_depth, int64_t first, int32_t count,
+                       double *events9, uint8_t *valid);
 
 /* Function-level probe used by parity tests: objs[obj]->intersect(org, dir, len, normal) for n rays on the
  * device (host pointers; keys: per-ray stream key for Bezier draws, may be NULL). */

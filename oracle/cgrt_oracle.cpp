@@ -679,6 +679,13 @@ static void trace_store(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, i
 }
 
 // trace(flag=false), main.cpp:42-81,101-128,129-165
+struct EventLog {  // optional record of the diffuse photon hits, in serial order (function-level parity probe)
+    double *out = nullptr;  // 10 doubles each: photon index, P(3), n(3), flux(3)
+    uint64_t cap = 0, n = 0;
+    int64_t photon = 0;
+};
+static EventLog *g_evlog = nullptr;
+
 static void trace_photon(const Scene &sc, const V3 &org, const V3 &dir, V3 flux, V3 adj, int depth_left, Rng &rng,
                          HashGrid &ht, double alpha, Sink &sink) {
     if (depth_left <= 0) return;
@@ -699,6 +706,15 @@ static void trace_photon(const Scene &sc, const V3 &org, const V3 &dir, V3 flux,
     if (obj.kind == PLANE && obj.tex >= 0) { V3 c; if (sc.textures[obj.tex]->color(P, c)) f = c; }
     double p = max3(f.x, f.y, f.z);  // main.cpp:79
     if (obj.refl < EPS && obj.transp < EPS) {
+        if (g_evlog) {
+            if (g_evlog->n < g_evlog->cap) {
+                double *e = g_evlog->out + 10 * g_evlog->n;
+                e[0] = (double)g_evlog->photon;
+                e[1] = P.x; e[2] = P.y; e[3] = P.z; e[4] = normalvec.x; e[5] = normalvec.y; e[6] = normalvec.z;
+                e[7] = flux.x; e[8] = flux.y; e[9] = flux.z;
+            }
+            g_evlog->n++;
+        }
         int ix, iy, iz;
         ht.coord(P.x, P.y, P.z, ix, iy, iz);
         ix -= 1; iy -= 1; iz -= 1;
@@ -1052,6 +1068,34 @@ double orc_trace_grid(void *sp, const orc_camera *cam, const orc_grid *g, int ha
     if (nrays) *nrays = total_rays;
     if (hp_count) *hp_count = total_hp;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// diffuse photon hits of photons [first, first+count) in serial order: 10 doubles each (photon, P, n, flux)
+uint64_t orc_photon_events(void *sp, const orc_photons *ph, int depth, int64_t first, int64_t count, double *out,
+                           uint64_t cap) {
+    Scene *s = (Scene *)sp;
+    HashGrid ht(1, 200.0 / 768);
+    Sink sink;
+    double dummy_acc[3] = {0, 0, 0};
+    uint32_t dummy_hit = 0;
+    sink.acc = dummy_acc;
+    sink.nhit = &dummy_hit;
+    EventLog log;
+    log.out = out;
+    log.cap = cap;
+    g_evlog = &log;
+    V3 light = v3(ph->light);
+    for (int64_t i = first; i < first + count; i++) {
+        log.photon = i;
+        Rng rng{cgrt_key(ph->seed, (uint64_t)i, 0, CGRT_PURPOSE_PHOTON), 0};
+        double a = rng.u01() * (2 * ph->jitter) - ph->jitter;
+        double b = rng.u01() * (2 * ph->jitter) - ph->jitter;
+        V3 dir = sample_sphere(rng);
+        trace_photon(*s, light + V3(a, 0, b), dir, V3(ph->power, ph->power, ph->power) * (PI_REF * 4.0), V3(1, 1, 1), depth, rng, ht,
+                     ph->alpha, sink);
+    }
+    g_evlog = nullptr;
+    return log.n;
 }
 
 // eye pass + serial photon pass + final gather; same signature and record layout as ref_ppm (cgrt_testapi.h)

@@ -86,6 +86,10 @@ class Backend:
         f("tree_dump").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         f("plane_bump_ntris").argtypes = [C.c_void_p, C.c_int]
         f("plane_bump_tris").argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if prefix == "orc":
+            L.orc_photon_events.restype = C.c_uint64
+            L.orc_photon_events.argtypes = [C.c_void_p, C.POINTER(OrcPhotons), C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                            C.c_uint64]
         f("ppm").restype = C.c_int64
         f("ppm").argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.POINTER(OrcGrid), C.POINTER(OrcPhotons), C.c_void_p,
                              C.c_uint64, C.c_void_p]
@@ -190,6 +194,13 @@ class BackendScene:
         hp = hp[:n]
         order = np.lexsort([hp[:, 7], hp[:, 6], hp[:, 5], hp[:, 1], hp[:, 0]])
         return dict(hp=hp[order], image=img, n=int(n))
+
+    def photon_events(self, first, count, depth=5, photon_seed=777, light=(0.0, 19.999, 20.0), jitter=2.0, power=700.0):
+        """Oracle only: the diffuse hits of photons [first, first+count) in serial order, [n,10] = photon, P, n, flux."""
+        ph = OrcPhotons(_d3(light), jitter, power, 0.7, count, 1000001, 0, photon_seed)
+        out = np.zeros((count * 8, 10), np.float64)
+        n = self.be.lib.orc_photon_events(self.h, C.byref(ph), depth, first, count, out.ctypes.data, count * 8)
+        return out[: int(n)]
 
     def intersect_batch(self, obj, org, dirs, keys=None):
         org = np.ascontiguousarray(org, np.float64)
