@@ -37,6 +37,12 @@ class Photons(C.Structure):
                 ("nphotons", C.c_int64), ("hashsize", C.c_int32), ("batch", C.c_int32), ("seed", C.c_uint64)]
 
 
+class PpmResult(C.Structure):
+    _fields_ = [("image", C.c_void_p), ("rgb8", C.c_void_p), ("hp16", C.c_void_p), ("hp_cap", C.c_uint64),
+                ("hp_count", C.c_uint64), ("n_events", C.c_uint64), ("n_pairs", C.c_uint64), ("ms_eye", C.c_double),
+                ("ms_table", C.c_double), ("ms_photons", C.c_double), ("ms_gather", C.c_double)]
+
+
 class SceneStats(C.Structure):
     _fields_ = [("n_objects", C.c_int32), ("n_spheres", C.c_int32), ("n_planes", C.c_int32),
                 ("n_meshes", C.c_int32), ("n_beziers", C.c_int32), ("n_textures", C.c_int32),
@@ -71,8 +77,10 @@ SIGNATURES = {
                                        C.c_void_p]),
     "cgrt_trace_grid_hitpoints": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_uint64,
                                             C.POINTER(C.c_uint64)]),
-    "cgrt_ppm_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.POINTER(Photons), C.c_void_p,
-                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cgrt_ppm_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.POINTER(Photons),
+                                  C.POINTER(PpmResult)]),
+    "cgrt_tonemap_rgb8": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cgrt_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_void_p]),
     "cgrt_photon_events": (C.c_int, [C.c_void_p, C.POINTER(Photons), C.c_int, C.c_int64, C.c_int32, C.c_void_p,
                                      C.c_void_p]),
     "cgrt_lens_samples": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),

@@ -413,7 +413,7 @@ __device__ __forceinline__ V3 bez_normal(const BezierRec &b, double u, double sn
 
 // The ten solves of Bezier::intersect (bezier.h:233-271), one lane, strictly sequential draws: the reference's
 // exact semantics including the jitter branch.  Used by the function-level fallback below.
-__device__ bool bezier_solve_serial(const BezierRec &b, V3 pos, V3 o, V3 d, Stream rs, double &len, V3 &n) {
+__device__ bool bezier_solve_serial(const BezierRec &b, V3 pos, V3 o, V3 d, Stream &rs, double &len, V3 &n) {
     bool flag = false;
     len = kInf;
     for (int k = 0; k < 10; k++) {  // num_of_samples_newton, bezier.h:27
@@ -457,8 +457,11 @@ struct BezLds {
     uint8_t lane_of_rank[64];
 };
 
-__device__ bool bezier_wave(const BezierRec &b, V3 pos, double cap_r, bool on, V3 o, V3 d, uint64_t key, double &len,
-                            V3 &n, volatile BezLds *L) {
+// `n0`: position of the ray's first draw in the stream `key` (0 for the eye pass, whose Bezier streams are keyed per ray;
+// the photon pass continues the photon's own sequential stream, as the reference's rand() does).  On return `n0` has
+// advanced by the draws the reference would have consumed (0 when the ray misses the box).
+__device__ bool bezier_wave(const BezierRec &b, V3 pos, double cap_r, bool on, V3 o, V3 d, uint64_t key, uint32_t &n0,
+                            double &len, V3 &n, volatile BezLds *L) {
     const int lane = threadIdx.x & 63;
     const bool want = on && bez_box(b, o, d);
     const unsigned long long wm = __ballot(want);
@@ -495,13 +498,21 @@ __device__ bool bezier_wave(const BezierRec &b, V3 pos, double cap_r, bool on, V
                 const V3 fo = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
                 const V3 fd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
                 const unsigned long long fkey = __shfl((unsigned long long)key, src);
+                const uint32_t fn0 = (uint32_t)__shfl((int)n0, src);
                 if (take) {
                     so = fo;
                     sd = fd;
                     task = t;
-                    const uint64_t z = fin64(fkey + (uint64_t)(t % 10 + 1) * kGolden);
-                    const double u0 = div_rand_max((uint32_t)(z >> 33));
-                    const double t0 = 20 + 10 * div_rand_max((uint32_t)((z >> 2) & 0x7fffffffu));
+                    Stream ts(fkey);
+                    ts.n = fn0 + 2u * (uint32_t)(t % 10);
+                    double u0, t0;
+                    if ((ts.n & 1u) == 0u) {
+                        ts.pair(u0, t0);  // both draws from one finaliser
+                    } else {
+                        u0 = ts.u01();
+                        t0 = ts.u01();
+                    }
+                    t0 = 20 + 10 * t0;
                     newton_init(b, pos, so, sd, u0, t0, st);
                     busy = true;
                 }
@@ -547,7 +558,14 @@ __device__ bool bezier_wave(const BezierRec &b, V3 pos, double cap_r, bool on, V
             }
         }
     }
-    if (redo) flag = bezier_solve_serial(b, pos, o, d, Stream(key), len, n);
+    if (redo) {
+        Stream rs(key);
+        rs.n = n0;
+        flag = bezier_solve_serial(b, pos, o, d, rs, len, n);
+        n0 = rs.n;
+    } else if (want) {
+        n0 += 20u;
+    }
     if (want) {
         n = (dot(n, d) < 0) ? n : -n;  // bezier.h:272
         double newt = b.box[3] - o.y;  // ymax - rayorig.y, bezier.h:273-281
@@ -578,6 +596,7 @@ struct RayKey {
     uint64_t k;  // the sample's key k_smp (cgrt_rng.hpp), or the explicit stream key
     uint32_t path;
     bool explicit_key;
+    uint32_t n0;  // explicit key only: position in the stream; advanced by the draws consumed (photon pass)
 };
 
 // Sphere::intersect, objects.h:45-68: the hit distance, or +inf-like kInf (never < nearest) on a miss
@@ -635,7 +654,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
 
 template <bool TREES, bool BEZ, bool SPH, bool STATS>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
-                                                    V3 o, V3 d, const RayKey &rk, bool on, const LdsAux &aux,
+                                                    V3 o, V3 d, RayKey &rk, bool on, const LdsAux &aux,
                                                     uint32_t &n_node, uint32_t &n_tri) {
     SceneHit best;
     best.t = kInf;  // `nearest = INF`, main.cpp:54
@@ -713,7 +732,10 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             const uint64_t key = rk.explicit_key ? rk.k : purpose_key(rk.k, ((uint64_t)rk.path << 16) | (uint64_t)(i + 1));
             double len = 0;
             V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
-            if (bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, len, nrm, aux.bl)) {
+            uint32_t n0 = rk.explicit_key ? rk.n0 : 0u;
+            const bool bh = bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, n0, len, nrm, aux.bl);
+            if (rk.explicit_key) rk.n0 = n0;
+            if (bh) {
                 if (len < best.t) {
                     best.t = len;
                     best.id = i;
@@ -850,7 +872,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) voi
         wave_iters++;
         // All 64 lanes enter the scene walk together (lanes without a ray carry on == false): the object list
         // is wave-uniform, so its control flow stays scalar.
-        const RayKey rk{k_smp, path, false};
+        RayKey rk{k_smp, path, false, 0u};
         const SceneHit hit =
             intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
         if (have) {
@@ -1040,7 +1062,7 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     uint32_t a = 0, b = 0;
     const V3 o = ld3(org + 3 * ii), d = ld3(dir + 3 * ii);
     DeviceScene one = sc;
-    const RayKey rk{keys ? keys[ii] : 0ull, 1, true};
+    RayKey rk{keys ? keys[ii] : 0ull, 1, true, 0u};
     const LdsAux aux{&bl, nullptr};
     SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, one, o, d, rk, on, aux, a, b);
     if (!on) return;
@@ -1361,12 +1383,12 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     return CGRT_OK;
 }
 
-int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, double *hp10,
-                              uint64_t cap, uint64_t *count) {
-    int rc = check_grid(s, cam, grid);
-    if (rc) return rc;
-    if (!count || (cap > 0 && !hp10)) return fail(CGRT_ERR_INVALID, "null output");
-    HIP_TRY(hipSetDevice(s->device));
+}  // extern "C"
+
+// Eye pass with Hitpoint capture into a device buffer of `cap` records (10 doubles each); *count = hitpoints produced.
+// *d_rec_out is hipMalloc'ed here (caller frees) unless cap == 0.
+static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, uint64_t cap,
+                            double **d_rec_out, uint64_t *count) {
     GridParams g;
     g.W = grid->width; g.H = grid->height; g.rows = grid->rows; g.row_offset = grid->row_offset;
     g.stripe_rows = grid->stripe_rows; g.stripe_rank = grid->stripe_rank; g.stripe_nranks = grid->stripe_nranks;
@@ -1396,17 +1418,37 @@ int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const
     else
         hipLaunchKernelGGL((trace_grid_kernel<true, true, false, true, false, false, true>), grid_dim, block, lds, 0,
                            s->dev, g, d_rgb, (uint32_t *)nullptr, (unsigned long long *)nullptr, sink);
+    int rc = CGRT_OK;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) rc = fail(CGRT_ERR_DEVICE, std::string("hitpoint kernel: ") + hipGetErrorString(e));
     unsigned long long n = 0;
+    if (rc == CGRT_OK && hipMemcpy(&n, d_cnt, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(CGRT_ERR_DEVICE, "hitpoint count copy");
+    *count = n;
+    (void)hipFree(d_rgb); (void)hipFree(d_cnt);
+    if (rc == CGRT_OK && cap && d_rec_out) *d_rec_out = d_rec; else (void)hipFree(d_rec);
+    return rc;
+}
+
+extern "C" {
+
+int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, double *hp10,
+                              uint64_t cap, uint64_t *count) {
+    int rc = check_grid(s, cam, grid);
+    if (rc) return rc;
+    if (!count || (cap > 0 && !hp10)) return fail(CGRT_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(s->device));
+    double *d_rec = nullptr;
+    uint64_t n = 0;
+    rc = hitpoints_device(s, cam, grid, cap, &d_rec, &n);
     if (rc == CGRT_OK) {
-        HIP_TRY(hipMemcpy(&n, d_cnt, sizeof(n), hipMemcpyDeviceToHost));
         *count = n;
-        const unsigned long long m = n < cap ? n : cap;
-        if (m) HIP_TRY(hipMemcpy(hp10, d_rec, (size_t)m * 10 * sizeof(double), hipMemcpyDeviceToHost));
+        const uint64_t m = n < cap ? n : cap;
+        if (m && hipMemcpy(hp10, d_rec, (size_t)m * 10 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(CGRT_ERR_DEVICE, "hitpoint copy");
     }
-    (void)hipFree(d_rgb); (void)hipFree(d_rec); (void)hipFree(d_cnt);
+    if (d_rec) (void)hipFree(d_rec);
     return rc;
 }
 

@@ -3,6 +3,7 @@ launches the eye pass (the loop nest of main.cpp:185-219) on the GPU."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -164,20 +165,26 @@ class Scene:
 
     def ppm_render(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, nphotons=100000, photon_seed=777,
                    hashsize=1000001, light=(0.0, 19.999, 20.0), jitter=2.0, power=700.0, alpha=0.7, batch=0,
-                   want_hitpoints=False):
-        """Eye pass + photon pass + final gather (render(), main.cpp:169-258, serial photon semantics).
-        Returns dict(image [H,W,3] float64, and with want_hitpoints: hp [n,16])."""
+                   want_hitpoints=False, want_rgb8=False):
+        """Eye pass + photon pass + final gather (+ tone map): render() main.cpp:169-258 with the serial photon
+        semantics, and the PNG pixel loop of main.cpp:403-412.
+        Returns dict(image [H,W,3] float64 (row 0 = bottom), count, n_events, n_pairs, ms (stage times); with
+        want_hitpoints: hp [n,16]; with want_rgb8: rgb8 [H,W,3] uint8, top row first)."""
         cc, g = self._structs(camera, width, height, height, spp, max_depth, seed, 0, None, 0, None, 0)
         ph = _capi.Photons(_d3(light), jitter, power, alpha, nphotons, hashsize, batch, photon_seed)
         img = np.zeros((height, width, 3), np.float64)
-        n = C.c_uint64(0)
         cap = height * width * spp * 16 if want_hitpoints else 0
         hp = np.zeros((max(cap, 1), 16), np.float64)
-        check(self._L.cgrt_ppm_render(self._h, C.byref(cc), C.byref(g), C.byref(ph), img.ctypes.data,
-                                      hp.ctypes.data if want_hitpoints else None, cap, C.byref(n)))
-        out = dict(image=img, count=int(n.value))
+        rgb8 = np.zeros((height, width, 3), np.uint8)
+        res = _capi.PpmResult(img.ctypes.data, rgb8.ctypes.data if want_rgb8 else None,
+                              hp.ctypes.data if want_hitpoints else None, cap)
+        check(self._L.cgrt_ppm_render(self._h, C.byref(cc), C.byref(g), C.byref(ph), C.byref(res)))
+        out = dict(image=img, count=int(res.hp_count), n_events=int(res.n_events), n_pairs=int(res.n_pairs),
+                   ms=dict(eye=res.ms_eye, table=res.ms_table, photons=res.ms_photons, gather=res.ms_gather))
         if want_hitpoints:
-            out["hp"] = hp[: int(n.value)]
+            out["hp"] = hp[: int(res.hp_count)]
+        if want_rgb8:
+            out["rgb8"] = rgb8
         return out
 
     def photon_events(self, first, count, max_depth=5, photon_seed=777, light=(0.0, 19.999, 20.0), jitter=2.0,
@@ -215,3 +222,20 @@ def render(objs, width=1024, height=768, num_of_samples=1, camera=None, max_dept
         return sc.trace_grid_host(width, height, num_of_samples, camera, max_depth, seed)["rgb"]
     finally:
         sc.close()
+
+
+def tonemap_rgb8(image, device=0):
+    """gammaCorr + vertical flip (util.h:45-47, main.cpp:403-412) on the device: [H,W,3] float64, row 0 = bottom ->
+    [H,W,3] uint8, top row first."""
+    image = np.ascontiguousarray(image, np.float64)
+    h, w = image.shape[:2]
+    out = np.zeros((h, w, 3), np.uint8)
+    check(_capi.lib().cgrt_tonemap_rgb8(device, image.ctypes.data, w, h, out.ctypes.data))
+    return out
+
+
+def write_png(path, rgb8):
+    """stbi_write_png's role at main.cpp:412: [H,W,3] uint8, top row first."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    h, w = rgb8.shape[:2]
+    check(_capi.lib().cgrt_write_png(os.fsencode(path), w, h, rgb8.ctypes.data))

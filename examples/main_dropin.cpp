@@ -4,6 +4,7 @@
 //
 //   cgrt_main [--scene c2|planes|chess|vase] [--mesh FILE TYPE] [--width W] [--height H] [--spp N] [--dof] [--depth D]
 //             [--raw out.f32] [--ppm out.ppm]
+//             [--photons N --png test.png]   the whole of render() + main(): photon pass, gather, tone map, PNG
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +21,8 @@ int main(int argc, char *argv[]) {
     RenderParams rp;
     rp.width = 256;
     rp.height = 192;
-    std::string scene = "c2", raw, ppm, mesh_file;
+    std::string scene = "c2", raw, ppm, mesh_file, png;
+    long long photons = 0;
     int mesh_type = 0;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -34,6 +36,8 @@ int main(int argc, char *argv[]) {
         else if (a == "--dof") rp.depth_of_field = true;
         else if (a == "--raw") raw = next();
         else if (a == "--ppm") ppm = next();
+        else if (a == "--png") png = next();
+        else if (a == "--photons") photons = std::atoll(next());
     }
 
     vector<Object *> objs;
@@ -88,6 +92,26 @@ int main(int argc, char *argv[]) {
     Bezier vase(cp, Vec3(15, -10.1, 35), Vec3(1.0, 1.0, 1.0), 0.5, 0.0);
     if (scene == "vase") objs.push_back(&vase);
 
+    if (photons > 0) {  // render() as the reference runs it, then main()'s PNG loop (main.cpp:403-412)
+        PhotonParams pp;
+        pp.num_photon = photons;
+        pp.num_threads = 1;
+        vector<double> img;
+        vector<unsigned char> image_data;
+        PpmStats ps;
+        try {
+            render_ppm(objs, rp, pp, img, image_data, &ps);
+            if (!png.empty()) write_png(png.c_str(), rp.width, rp.height, image_data);
+        } catch (const Error &e) {
+            std::fprintf(stderr, "render failed (%d): %s\n", e.code, e.what());
+            return 1;
+        }
+        std::printf("\nhitpoints: %llu\n", (unsigned long long)ps.hitpoints);  // main.cpp:265
+        std::printf("photon events: %llu; eye %.2f ms, table %.2f ms, photons %.2f ms, gather %.2f ms\n",
+                    (unsigned long long)ps.photon_events, ps.ms_eye, ps.ms_table, ps.ms_photons, ps.ms_gather);
+        delete tm;
+        return 0;
+    }
     vector<float> image;
     RenderStats st;
     try {

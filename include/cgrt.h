@@ -181,12 +181,34 @@ typedef struct cgrt_photons {
     uint64_t seed;
 } cgrt_photons;
 
-/* Eye pass + photon pass + final gather for grid (contiguous rows only; Bezier objects not yet supported).
- * image: HOST buffer rows*width*3 doubles, image[h][w] = sum over the pixel's hitpoints of flux / (PI * r2 * nphotons * spp)
- * (main.cpp:256).  hp16 (optional, HOST): per hitpoint 16 doubles {pixel*spp+sample, emission index, f(3), pos(3),
- * normal(3), flux(3), r2, n} in the reference's table order. */
+/* What cgrt_ppm_render hands back; every pointer is a HOST buffer owned by the caller and may be NULL. */
+typedef struct cgrt_ppm_result {
+    double *image;     /* rows*width*3: image[h][w] = sum over the pixel's hitpoints of flux / (PI * r2 * nphotons * spp),
+                        * row 0 = bottom (main.cpp:252-258)                                                        */
+    uint8_t *rgb8;     /* rows*width*3: the PNG pixels of main.cpp:403-412 -- top row first, gammaCorr() per channel
+                        * (row f2; same values as cgrt_tonemap_rgb8(image))                                        */
+    double *hp16;      /* hp_cap x 16: per hitpoint {pixel*spp+sample, emission index, f(3), pos(3), normal(3), flux(3),
+                        * r2, n} in the reference's table order (bucket, then insertion order)                     */
+    uint64_t hp_cap;
+    uint64_t hp_count; /* out: hitpoints the eye pass produced                                                     */
+    uint64_t n_events; /* out: diffuse photon hits processed (main.cpp:103-125 executions)                         */
+    uint64_t n_pairs;  /* out: (hitpoint, photon hit) candidate pairs replayed                                      */
+    double ms_eye, ms_table, ms_photons, ms_gather; /* out: device time of the four stages, milliseconds            */
+} cgrt_ppm_result;
+
+/* Eye pass + photon pass + final gather (+ tone map) for grid: the whole of render(), main.cpp:169-258, and the pixel
+ * loop of main(), main.cpp:403-412.  Contiguous rows only (the hash table is global to the frame). */
 int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, const cgrt_photons *ph,
-                    double *image, double *hp16, uint64_t hp_cap, uint64_t *hp_count);
+                    cgrt_ppm_result *out);
+
+/* ---- row f2 of SURVEY.md section 8: tone map, flip, PNG (util.h:45-47, main.cpp:403-412) ----------------------
+ * rgb8[(height-1-h)*width + w][c] = int(pow(1 - exp(-image[h][w][c]), 1/2.2) * 255 + .5) computed on `device`;
+ * HOST buffers.  NaN and negative inputs give 0 (the reference's int(NaN) is undefined). */
+int cgrt_tonemap_rgb8(int device, const double *image, int width, int height, uint8_t *rgb8);
+
+/* 8-bit RGB PNG, rows top to bottom, like stbi_write_png("test.png", width, height, 3, data, width*3) at main.cpp:412.
+ * Self-contained encoder (stored deflate blocks; no zlib dependency).  Host only. */
+int cgrt_write_png(const char *path, int width, int height, const uint8_t *rgb8);
 
 /* Verification probe for photon paths: the diffuse hits (the events the serial loop of main.cpp:103-125 processes) of
  * photons [first, first+count): events9 = count*8 slots of 9 doubles {P(3), n(3), flux(3)}, slot = (photon-first)*8 +

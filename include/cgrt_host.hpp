@@ -246,8 +246,8 @@ struct RenderStats {
 };
 
 // Eye pass of render(objs): image[h][w] (row 0 = bottom, main.cpp:185-189) receives, per channel, the sum of
-// hp.f over the pixel's hitpoints divided by num_of_samples, as float RGB.  (The photon pass and tone mapping
-// that follow in the reference, main.cpp:223-258, are outside this library's scope.)
+// hp.f over the pixel's hitpoints divided by num_of_samples, as float RGB.  (For the photon pass and tone mapping
+// that follow in the reference, main.cpp:223-258, see render_ppm below.)
 inline void render(const std::vector<Object *> &objs, const RenderParams &rp, std::vector<float> &image,
                    RenderStats *stats = nullptr) {
     SceneBuilder sb;
@@ -274,6 +274,73 @@ inline void render(const std::vector<Object *> &objs, const RenderParams &rp, st
         stats->rays = cnt[CGRT_CNT_RAYS];
         stats->hitpoints = cnt[CGRT_CNT_HITPOINTS];
     }
+}
+
+// ---- the whole of render() + main()'s PNG loop: main.cpp:169-258, 403-412 ---------------------------------------
+// Photon-pass constants of the reference as runtime fields with the same defaults.
+struct PhotonParams {
+    Vec3 lightorg = Vec3(0, 19.999, 20);   // main.cpp:180
+    double jitter = 2.0;                   // main.cpp:240-241 (u*4-2)
+    double power = 700.0;                  // main.cpp:246
+    double alpha = 0.7;                    // main.cpp:36
+    long long num_photon = 2560000;        // main.cpp:223
+    int num_threads = 8;                   // main.cpp:224: total photons = num_photon * num_threads
+    int hashsize = 1000001;                // main.cpp:184
+    uint64_t seed = 777;
+};
+struct PpmStats {
+    uint64_t hitpoints = 0, photon_events = 0;
+    double ms_eye = 0, ms_table = 0, ms_photons = 0, ms_gather = 0;
+};
+
+// render(objs) as the reference runs it: eye pass, photon pass (serial semantics: photon i on the keyed stream
+// (seed, i); the reference's racing OpenMP threads over time-seeded rand() have no reproducible meaning), final
+// gather into image[h][w] (doubles, row 0 = bottom, main.cpp:252-258) and the tone-mapped, flipped bytes that
+// main.cpp:403-411 hands to stbi_write_png.
+inline void render_ppm(const std::vector<Object *> &objs, const RenderParams &rp, const PhotonParams &pp,
+                       std::vector<double> &image, std::vector<unsigned char> &image_data, PpmStats *stats = nullptr) {
+    SceneBuilder sb;
+    for (const Object *o : objs) o->add_to(sb);
+    check(cgrt_scene_commit(sb.scene, rp.device));
+    cgrt_camera cam;
+    rp.camorg.get(cam.cam);
+    cam.half_width = 10.0;
+    cam.focus_plane = rp.focus_plane;
+    cam.lens_radius = rp.depth_of_field ? rp.radius : 0.0;
+    cgrt_grid g{};
+    g.width = rp.width;
+    g.height = rp.height;
+    g.rows = rp.height;
+    g.stripe_nranks = 1;
+    g.spp = rp.num_of_samples;
+    g.spp_total = rp.num_of_samples;
+    g.max_depth = rp.max_depth;
+    g.seed = rp.seed;
+    cgrt_photons ph{};
+    pp.lightorg.get(ph.light);
+    ph.jitter = pp.jitter;
+    ph.power = pp.power;
+    ph.alpha = pp.alpha;
+    ph.nphotons = pp.num_photon * pp.num_threads;
+    ph.hashsize = pp.hashsize;
+    ph.seed = pp.seed;
+    image.assign((size_t)rp.width * rp.height * 3, 0.0);
+    image_data.assign((size_t)rp.width * rp.height * 3, 0);
+    cgrt_ppm_result out{};
+    out.image = image.data();
+    out.rgb8 = image_data.data();
+    check(cgrt_ppm_render(sb.scene, &cam, &g, &ph, &out));
+    if (stats) {
+        stats->hitpoints = out.hp_count;
+        stats->photon_events = out.n_events;
+        stats->ms_eye = out.ms_eye; stats->ms_table = out.ms_table;
+        stats->ms_photons = out.ms_photons; stats->ms_gather = out.ms_gather;
+    }
+}
+
+// stbi_write_png("test.png", width, height, 3, image_data, width * 3), main.cpp:412
+inline void write_png(const char *path, int width, int height, const std::vector<unsigned char> &image_data) {
+    check(cgrt_write_png(path, width, height, image_data.data()));
 }
 
 }  // namespace cgrt_host

@@ -1161,4 +1161,16 @@ int64_t orc_ppm(void *sp, const orc_camera *cam, const orc_grid *g, const orc_ph
     return k;
 }
 
+// tone map + flip, main.cpp:403-411 with gammaCorr (util.h:45-47): int(pow(1-exp(-x),1/2.2)*255+.5) stored to a byte.
+// image: H*W*3 doubles, row 0 = bottom; out: H*W*3 bytes, top row first.
+void orc_tonemap(const double *image, int W, int H, uint8_t *out) {
+    size_t counter = 0;
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const double *px = image + ((size_t)(H - i - 1) * W + j) * 3;
+            for (int k = 0; k < 3; k++) out[3 * counter + k] = (uint8_t)(int)(std::pow(1 - std::exp(-px[k]), 1 / 2.2) * 255 + .5);
+            counter++;
+        }
+}
+
 }  // extern "C"

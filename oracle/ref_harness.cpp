@@ -404,4 +404,18 @@ int64_t ref_ppm(void *sp, const orc_camera *cam, const orc_grid *g, const orc_ph
     return k;
 }
 
+// ---- tone map + flip: the PNG pixel loop of main(), main.cpp:403-411, with the reference's own gammaCorr (util.h:45-47)
+// image: H*W*3 doubles, row 0 = bottom; out: H*W*3 bytes, top row first
+void ref_tonemap(const double *image, int W, int H, uint8_t *out) {
+    size_t counter = 0;
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const double *px = image + ((size_t)(H - i - 1) * W + j) * 3;
+            out[3 * counter] = gammaCorr(px[0]);
+            out[3 * counter + 1] = gammaCorr(px[1]);
+            out[3 * counter + 2] = gammaCorr(px[2]);
+            counter++;
+        }
+}
+
 }  // extern "C"

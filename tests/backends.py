@@ -90,6 +90,8 @@ class Backend:
             L.orc_photon_events.restype = C.c_uint64
             L.orc_photon_events.argtypes = [C.c_void_p, C.POINTER(OrcPhotons), C.c_int, C.c_int64, C.c_int64, C.c_void_p,
                                             C.c_uint64]
+        f("tonemap").restype = None
+        f("tonemap").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         f("ppm").restype = C.c_int64
         f("ppm").argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.POINTER(OrcGrid), C.POINTER(OrcPhotons), C.c_void_p,
                              C.c_uint64, C.c_void_p]
@@ -100,6 +102,14 @@ class Backend:
     def set_threads(self, n):
         if self.prefix == "orc":
             self.lib.orc_set_threads(int(n))
+
+    def tonemap(self, image):
+        """main.cpp:403-411 + gammaCorr: [H,W,3] float64 (row 0 = bottom) -> [H,W,3] uint8 (top row first)."""
+        image = np.ascontiguousarray(image, np.float64)
+        h, w = image.shape[:2]
+        out = np.zeros((h, w, 3), np.uint8)
+        self.f("tonemap")(image.ctypes.data, w, h, out.ctypes.data)
+        return out
 
 
 class BackendScene:

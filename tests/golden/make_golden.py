@@ -58,6 +58,24 @@ def photon_cases():
     ]
 
 
+def photon_cases_bezier():
+    """The Bezier vase (mirror-like, main.cpp:371-376) hidden from the camera behind a diffuse sphere: no eye ray's
+    nearest hit is on the vase, so the eye pass does not depend on Newton draws, while photons from the ceiling
+    light do reach it and take their Newton starts from the photon's own sequential stream, exactly like the
+    reference's rand().  Pins the oracle's photon-pass Bezier bit for bit against the compiled reference."""
+    S = scenes
+    hidden = lambda: S.planes() + [S.Sphere((7.5, -5.0, 12.5), 7.5, (0.3, 0.3, 0.3), 0.0, 0.0), S.vase_bezier()]
+    return [("vase_hidden_40x30", hidden, S.cam_pinhole, 40, 30, 1, 6000)]
+
+
+def tonemap_input():
+    """Pixel values for the tone-map fixture: linear and log-spaced radiances, exact 0, saturation, and a dense sweep
+    across every 8-bit output step."""
+    rng = np.random.default_rng(5)
+    return np.concatenate([rng.random((20, 31, 3)) * 3, 10 ** rng.uniform(-6, 2, (20, 31, 3)), np.zeros((1, 31, 3)),
+                           np.full((1, 31, 3), 50.0), np.linspace(0, 8, 3 * 31 * 60).reshape(60, 31, 3)])
+
+
 def fingerprint(nodes, leaf):
     sizes = nodes[:, 2]
     leaves = sizes[sizes < 10]
@@ -217,11 +235,14 @@ def main():
     np.savez_compressed(os.path.join(HERE, "trace_bezier_vase_48_statistical.npz"), acc_sum=r6["acc_sum"],
                         nhit=r6["nhit"], nrays=np.int64(r6["nrays"]))
     # ---- photon pass (row f1), serial keyed semantics: per-hitpoint (f,pos,normal,flux,r2,n) and the gathered image ----
-    for name, mk, cam, W, H, spp, nph in photon_cases():
+    for name, mk, cam, W, H, spp, nph in photon_cases() + photon_cases_bezier():
         s7 = BackendScene(ref, mk())
         r7 = s7.ppm(cam(), W, H, spp, 5, nphotons=nph)
         np.savez_compressed(os.path.join(HERE, "ppm_%s.npz" % name), hp=r7["hp"], image=r7["image"])
         print("ppm", name, r7["n"], float(r7["hp"][:, 15].max()))
+    # ---- tone map + flip (row f2): the reference's own gammaCorr and PNG pixel loop ----
+    timg = tonemap_input()
+    np.savez_compressed(os.path.join(HERE, "tonemap.npz"), image=timg, rgb8=ref.tonemap(timg))
     # ---- loaders: one process per file ----
     write_test_meshes()
     for name in LOADER_CASES:

@@ -158,3 +158,51 @@ def test_host_builder_under_sanitizers(tmp_path):
     assert "ERROR" not in out.stderr and "runtime error" not in out.stderr
     assert "bad.txt -> -2" in out.stdout  # malformed file refused
     assert "missing.txt -> " in out.stdout and "objs=" in out.stdout
+
+
+def _png_decode(path):
+    """Minimal PNG reader (8-bit RGB, filter 0 only -- what cgrt_write_png emits) with full CRC / Adler checks via zlib."""
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == bytes([0x89]) + b"PNG" + bytes([0x0d, 0x0a, 0x1a, 0x0a])
+    pos, chunks = 8, []
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + data) & 0xffffffff == crc, typ
+        chunks.append((typ, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype, comp, flt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, ctype, comp, flt, lace) == (8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 3 * w)  # checks adler32
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (7, 5), (300, 211), (768, 1024)])
+def test_write_png_round_trip(tmp_path, shape):
+    """cgrt_write_png (stbi_write_png's role at main.cpp:412) is host-only: a strict decode returns the same bytes;
+    PIL, where present, agrees."""
+    from cgraytracing_amd.engine import write_png
+    h, w = shape
+    img = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    path = str(tmp_path / "t.png")
+    write_png(path, img)
+    assert np.array_equal(_png_decode(path), img)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(np.asarray(Image.open(path).convert("RGB")), img)
+
+
+def test_write_png_errors(tmp_path):
+    from cgraytracing_amd import _capi
+    L = _capi.lib()
+    buf = np.zeros(12, np.uint8)
+    assert L.cgrt_write_png(None, 2, 2, buf.ctypes.data) == -1
+    assert L.cgrt_write_png(os.fsencode(str(tmp_path / "no_such_dir" / "x.png")), 2, 2, buf.ctypes.data) == -2
+    assert b"cannot open" in L.cgrt_last_error()

@@ -148,7 +148,10 @@ def test_depth_and_sample_ranges(orc):
     assert d1["nrays"] == 40 * 24
 
 
-@pytest.mark.parametrize("case", make_golden.photon_cases(), ids=[c[0] for c in make_golden.photon_cases()])
+PHOTON_CASES = make_golden.photon_cases() + make_golden.photon_cases_bezier()
+
+
+@pytest.mark.parametrize("case", PHOTON_CASES, ids=[c[0] for c in PHOTON_CASES])
 def test_photon_pass_matches_reference_golden(orc, case):
     """Row f1: eye pass + SERIAL photon pass + final gather.  The reference's own trace(flag=false),
     samplers and hash grid, run on one thread with rand() on the photons' keyed streams, are deterministic; the
@@ -161,3 +164,11 @@ def test_photon_pass_matches_reference_golden(orc, case):
     assert np.array_equal(r["hp"], g["hp"])
     assert np.array_equal(r["image"], g["image"])
     assert g["hp"][:, 15].max() > 10  # photons really were gathered
+
+
+def test_tonemap_matches_reference_golden(orc):
+    """Row f2: gammaCorr (util.h:45-47) and the flipped PNG pixel loop (main.cpp:403-411); fixture from the reference's own
+    gammaCorr."""
+    g = np.load(os.path.join(GOLD, "tonemap.npz"))
+    assert np.array_equal(orc.tonemap(g["image"]), g["rgb8"])
+    assert len(np.unique(g["rgb8"])) == 256  # every output level is exercised
