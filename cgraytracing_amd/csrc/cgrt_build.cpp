@@ -188,6 +188,41 @@ void HostTree::build() {
     b.emit(0, n, 0);
 }
 
+// Grid-ordered view of a bump floor's triangles (call after build()).
+void HostTree::build_hfield(int nx, int nz, double x0, double z0, double hx, double hz) {
+    const size_t ntri = tri9.size() / 9;
+    if (nx < 1 || nz < 1 || ntri != (size_t)nx * nz * 2 || tris.size() != ntri) return;
+    std::vector<int32_t> pos(ntri), leaf_of(ntri);
+    for (size_t k = 0; k < ntri; k++) pos[(size_t)leaf_ids[k]] = (int32_t)k;
+    int32_t seq = 0;
+    for (const NodeRec &nd : nodes)
+        if (nd.leaf >= 0) {
+            const int32_t first = nd.leaf >> 4, cnt = nd.leaf & 15;
+            for (int32_t k = first; k < first + cnt; k++) leaf_of[(size_t)k] = seq;
+            seq++;
+        }
+    hcells.resize((size_t)nx * nz);
+    double ylo = kInf, yhi = -kInf;
+    for (size_t c = 0; c < hcells.size(); c++)
+        for (int q = 0; q < 2; q++) {
+            const int32_t k = pos[2 * c + q];
+            hcells[c].t[q] = tris[(size_t)k];
+            hcells[c].k[q] = k;
+            hcells[c].leaf[q] = leaf_of[(size_t)k];
+            const double *t = &tri9[9 * (2 * c + q)];
+            for (int v = 0; v < 3; v++) {
+                if (t[3 * v + 1] < ylo) ylo = t[3 * v + 1];
+                if (t[3 * v + 1] > yhi) yhi = t[3 * v + 1];
+            }
+        }
+    hfield.cell_begin = 0;
+    hfield.nx = nx; hfield.nz = nz;
+    hfield.x0 = x0; hfield.z0 = z0;
+    hfield.hx = hx; hfield.hz = hz;
+    hfield.ylo = ylo; hfield.yhi = yhi;
+    is_hfield = true;
+}
+
 bool load_mesh_file(const char *file, double a, const double b[3], int type, std::vector<double> &tri9,
                     std::string &err) {
     tri9.clear();
@@ -301,6 +336,7 @@ int HostScene::add_plane(const double p[3], const double n[3], const double sc[3
                 for (const double *v : {D, B, Cc}) tree.tri9.insert(tree.tri9.end(), v, v + 3);
             }
         tree.build();
+        tree.build_hfield(C / step - 1, R / step - 1, tx.p[0], tx.p[2], tx.lenx * step / C, tx.leny * step / R);
         trees.push_back(std::move(tree));
         o.tree = (int)trees.size() - 1;
     }

@@ -20,7 +20,13 @@ struct HostTree {
     // device view
     std::vector<NodeRec> nodes;
     std::vector<TriRec> tris;
+    // bump floors only: the same triangles in grid order (construction order is cell-major: quad (i,j) = triangles
+    // 2*(i*nx+j) and +1), see HCellRec
+    bool is_hfield = false;
+    HFieldRec hfield{};
+    std::vector<HCellRec> hcells;
     void build();
+    void build_hfield(int nx, int nz, double x0, double z0, double hx, double hz);
 };
 
 struct HostTexture {

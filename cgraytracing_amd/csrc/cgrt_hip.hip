@@ -226,6 +226,107 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
     return r;
 }
 
+// =====================================================================================================
+// Opaque bump floors: the displacement mesh as a height field
+// =====================================================================================================
+// The reference pushes every floor-bound ray through its object-median tree over the bump mesh -- for the stone
+// floor 192 node tests and 179 triangle tests per ray on average, because both children are always visited and
+// preorder is not front to back.  The mesh is a regular grid of quads in x-z (objects.h:485-497), so for an OPAQUE
+// floor (where only the nearest hit matters, see PRUNE above) the ray is clipped to the slab of heights the mesh
+// occupies and walked column by column along its major horizontal axis; the two triangles of every cell the ray's
+// footprint touches are tested with the SAME triangle records and the SAME test as the tree's leaves, so an accepted
+// hit has the same `len`, bit for bit.  A hit point lies inside its triangle, hence over its cell, so the walk --
+// padded by kHfPad on every side against rounding -- meets every triangle the ray can hit; columns are visited in
+// ray order and the walk stops at the first column that begins beyond the nearest hit.  Exact ties (a ray through
+// a shared edge) are resolved as the tree resolves them: the triangle in the LATER leaf wins, inside a leaf the
+// EARLIER one (objects.h:281,297) -- each cell record carries its triangles' leaf number and leaf-order index.
+static constexpr double kHfPad = 1e-9;
+
+template <bool STATS>
+__device__ __forceinline__ TreeHit hfield_intersect(const HFieldRec &H, const HCellRec *__restrict__ cells, V3 o, V3 d,
+                                                    V3 inv, double bound, uint32_t &n_node, uint32_t &n_tri) {
+    TreeHit r;
+    r.len = kInf;
+    r.tri = -1;
+    r.counter = 0;
+    int best_leaf = -1;
+    // clip the ray's parameter range (0, bound] to the padded box of the mesh
+    double ta = 0.0, tb = bound;
+    const double lo[3] = {H.x0 - kHfPad, H.ylo - kHfPad, H.z0 - kHfPad};
+    const double hi[3] = {H.x0 + H.hx * H.nx + kHfPad, H.yhi + kHfPad, H.z0 + H.hz * H.nz + kHfPad};
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv.x, inv.y, inv.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (dd[k] != 0.0) {
+            const double t1 = (lo[k] - oo[k]) * ii[k], t2 = (hi[k] - oo[k]) * ii[k];
+            ta = fmax(ta, fmin(t1, t2));
+            tb = fmin(tb, fmax(t1, t2));
+        } else if (oo[k] < lo[k] || oo[k] > hi[k]) {
+            tb = -1.0;
+        }
+    }
+    if (!(ta <= tb)) return r;
+    // major axis: the one along which the ray crosses more cells
+    const bool xmaj = fabs(d.x) * H.hz >= fabs(d.z) * H.hx;
+    const double oM = xmaj ? o.x : o.z, dM = xmaj ? d.x : d.z, iM = xmaj ? inv.x : inv.z;
+    const double om = xmaj ? o.z : o.x, dm = xmaj ? d.z : d.x;
+    const double M0 = xmaj ? H.x0 : H.z0, hM = xmaj ? H.hx : H.hz, m0 = xmaj ? H.z0 : H.x0, hm = xmaj ? H.hz : H.hx;
+    const int nM = xmaj ? H.nx : H.nz, nm = xmaj ? H.nz : H.nx;
+    const double ihM = 1.0 / hM, ihm = 1.0 / hm;
+    const double Ma = oM + dM * ta, Mb = oM + dM * tb;
+    int j0 = (int)floor((fmin(Ma, Mb) - kHfPad - M0) * ihM), j1 = (int)floor((fmax(Ma, Mb) + kHfPad - M0) * ihM);
+    j0 = j0 < 0 ? 0 : j0;
+    j1 = j1 > nM - 1 ? nM - 1 : j1;
+    const int step = dM >= 0.0 ? 1 : -1;
+    const int jn = j1 - j0 + 1;  // columns to visit (<= 0: none)
+    int j = step > 0 ? j0 : j1;
+    for (int c = 0; c < jn; c++, j += step) {
+        // parameter range of the padded column, within [ta, tb]
+        double s0 = ta, s1 = tb;
+        if (dM != 0.0) {
+            const double t1 = (M0 + hM * j - kHfPad - oM) * iM, t2 = (M0 + hM * (j + 1) + kHfPad - oM) * iM;
+            s0 = fmax(s0, fmin(t1, t2));
+            s1 = fmin(s1, fmax(t1, t2));
+        }
+        if (s0 > r.len) break;   // this column and all later ones begin beyond the nearest hit
+        if (!(s0 <= s1)) continue;
+        const double ma = om + dm * s0, mb = om + dm * s1;
+        int i0 = (int)floor((fmin(ma, mb) - kHfPad - m0) * ihm), i1 = (int)floor((fmax(ma, mb) + kHfPad - m0) * ihm);
+        i0 = i0 < 0 ? 0 : i0;
+        i1 = i1 > nm - 1 ? nm - 1 : i1;
+        for (int i = i0; i <= i1; i++) {
+            if (STATS) n_node++;
+            const HCellRec *cell = cells + (xmaj ? (size_t)i * H.nx + j : (size_t)j * H.nx + i);
+            const int4 ids = *reinterpret_cast<const int4 *>(cell->k);  // k0 k1 leaf0 leaf1
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (STATS) n_tri++;
+                const V3 pa = ld3(cell->t[q].pa), e1 = ld3(cell->t[q].e1), e2 = ld3(cell->t[q].e2);
+                const V3 s = pa - o;
+                const double det1 = det3(d, e1, e2);
+                const double det2 = det3(s, e1, e2);
+                const double det3_ = det3(d, s, e2);
+                const double det4 = det3(d, e1, s);
+                const double sg = det1 > 0.0 ? 1.0 : -1.0;
+                const double a1 = det1 * sg;
+                const bool ok = (det1 != 0.0) && (det2 * sg > 0.0) && (det3_ * sg >= 0.0) && (det4 * sg >= 0.0) &&
+                                ((det3_ + det4) * sg <= a1);
+                if (ok) {
+                    const double len = det2 / det1;
+                    const int k = q ? ids.y : ids.x, leaf = q ? ids.w : ids.z;
+                    if (len < r.len || (len == r.len && (leaf > best_leaf || (leaf == best_leaf && k < r.tri)))) {
+                        r.len = len;
+                        r.tri = k;
+                        best_leaf = leaf;
+                        r.counter = 1;
+                    }
+                }
+            }
+        }
+    }
+    return r;
+}
+
 // normal of the winning triangle, oriented by the improvement-counter parity (objects.h:107,321-327)
 __device__ __forceinline__ V3 tree_normal(const TriRec *__restrict__ tris, const TreeHit &h, V3 d) {
     const V3 e1 = ld3(tris[h.tri].e1), e2 = ld3(tris[h.tri].e2);
@@ -641,6 +742,10 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     none.tri = -1;
     none.counter = 0;
     if (!on) return none;
+    if (opaque && T.hfield >= 0) {  // bump floor: walk the grid instead of the tree (same triangles, same test)
+        const HFieldRec H = sc.hfields[T.hfield];
+        return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, o, d, inv, bound, n_node, n_tri);
+    }
     const bool cached = aux.lnodes != nullptr && tr == sc.cached_tree;
     const NodeRec *nodes = sc.nodes + T.node_begin;
     const TriRec *tris = sc.tris + T.tri_begin;
@@ -1196,12 +1301,23 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     std::vector<NodeRec> nodes;
     std::vector<TriRec> tris;
     std::vector<TreeRec> trees;
+    std::vector<HFieldRec> hfields;
+    std::vector<HCellRec> hcells;
     for (auto &t : H.trees) {
         TreeRec tr;
         tr.node_begin = (int64_t)nodes.size();
         tr.tri_begin = (int64_t)tris.size();
         tr.nnodes = (int32_t)t.nodes.size();
         tr.ntris = (int32_t)t.tris.size();
+        tr.hfield = -1;
+        tr.pad = 0;
+        if (t.is_hfield) {
+            HFieldRec hf = t.hfield;
+            hf.cell_begin = (int64_t)hcells.size();
+            tr.hfield = (int32_t)hfields.size();
+            hfields.push_back(hf);
+            hcells.insert(hcells.end(), t.hcells.begin(), t.hcells.end());
+        }
         nodes.insert(nodes.end(), t.nodes.begin(), t.nodes.end());
         tris.insert(tris.end(), t.tris.begin(), t.tris.end());
         trees.push_back(tr);
@@ -1233,6 +1349,8 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     if ((rc = upload(s, texs, &d.texs))) return rc;
     if ((rc = upload(s, texels, &d.texels))) return rc;
     if ((rc = upload(s, H.beziers, &d.beziers))) return rc;
+    if ((rc = upload(s, hfields, &d.hfields))) return rc;
+    if ((rc = upload(s, hcells, &d.hcells))) return rc;
     d.n_objs = (int32_t)H.objs.size();
     d.n_trees = (int32_t)trees.size();
     d.n_texs = (int32_t)texs.size();

@@ -61,6 +61,27 @@ struct TreeRec {
     int64_t tri_begin;   // into tris[]
     int32_t nnodes;
     int32_t ntris;
+    int32_t hfield;      // bump floors: index into hfields[] (the same triangles as a regular grid), else -1
+    int32_t pad;
+};
+
+// A bump-mapped floor's displacement mesh (objects.h:482-503) is a height field over a regular x-z grid: one quad per
+// 3x3 texel block, split into triangles (a,b,c) and (d,b,c).  Besides the reference's tree, the triangles are kept in
+// GRID order so that an opaque floor can be traversed cell by cell along the ray: the same
+// triangle records and the same triangle test, hence the same (len, triangle); `k` and `leaf` carry each triangle's
+// place in the reference's leaf order, which decides exact ties (objects.h:281,297).
+struct HCellRec {
+    TriRec t[2];
+    int32_t k[2];     // index in the tree's leaf-ordered tris[] (relative to tri_begin)
+    int32_t leaf[2];  // sequence number of the leaf holding it
+};
+static_assert(sizeof(HCellRec) == 160, "HCellRec layout");
+struct HFieldRec {
+    int64_t cell_begin;  // into hcells[]: cell (i, j) at cell_begin + i * nx + j
+    int32_t nx, nz;      // cells along x (cols/3 - 1) and z (rows/3 - 1)
+    double x0, z0;       // texture position (vertex (0,0))
+    double hx, hz;       // cell pitch: lenx*3/cols, leny*3/rows
+    double ylo, yhi;     // range of vertex heights (plane y included)
 };
 
 struct TexRec {
@@ -89,6 +110,8 @@ struct DeviceScene {
     const TexRec *texs;
     const uint8_t *texels;
     const BezierRec *beziers;
+    const HFieldRec *hfields;
+    const HCellRec *hcells;
     int32_t n_objs, n_trees, n_texs, n_beziers;
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
     int32_t has_bezier;

@@ -257,3 +257,54 @@ def test_everything_at_once(gpu_ready, orc):
     assert ok.mean() >= 0.995
     assert abs(got["nrays"] - want["nrays"]) <= 0.005 * want["nrays"]
     assert hp["count"] == got["nhp"]
+
+
+def _bump_floor_rays(tex, n, seed):
+    """Rays aimed at a bump floor from everywhere: from above at all angles, grazing, from inside the layer of
+    heights, straight down, axis-aligned, and -- to force exact ties -- rays lying IN the vertical planes x = x_j and
+    z = z_i of the quad grid (vertex coordinates as objects.h:485-488 computes them), which cross shared edges."""
+    rng = np.random.default_rng(seed)
+    R, C = tex.data.shape[:2]
+    px, pz, lx, lz = tex.position[0], tex.position[2], tex.lenx, tex.leny
+    o = np.stack([rng.uniform(px - 3, px + lx + 3, n), rng.uniform(-20.2, 5.0, n), rng.uniform(pz - 3, pz + lz + 3, n)], 1)
+    tgt = np.stack([rng.uniform(px - 1, px + lx + 1, n), rng.uniform(-20.1, -19.4, n), rng.uniform(pz - 1, pz + lz + 1, n)], 1)
+    d = tgt - o
+    k = n // 8
+    o[:k, 1] = rng.uniform(-20.0, -19.5, k)                     # start inside the layer
+    d[k:2 * k] = [0.0, -1.0, 0.0]                                # straight down
+    d[2 * k:3 * k, 2] = 0.0                                      # in a plane z = const
+    d[3 * k:4 * k, 0] = 0.0                                      # in a plane x = const
+    jj = rng.integers(0, C // 3, k)
+    o[4 * k:5 * k, 0] = px + lx * jj * 3 / C                     # ... exactly on a grid line x = x_j
+    d[4 * k:5 * k, 0] = 0.0
+    ii = rng.integers(0, R // 3, k)
+    o[5 * k:6 * k, 2] = pz + lz * ii * 3 / R                     # ... exactly on a grid line z = z_i
+    d[5 * k:6 * k, 2] = 0.0
+    d[6 * k:7 * k, 1] *= 0.02                                    # grazing
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+@pytest.mark.parametrize("which", ["stone_small", "chessboard", "procedural_stone"])
+def test_bump_floor_grid_walk_vs_oracle(gpu_ready, orc, which):
+    """Plane::intersect with a bump map (objects.h:505-524) for an opaque floor runs the height-field walk on the
+    device while the oracle runs the reference's tree: hit flag and distance must be identical
+    bit for bit, the normal identical up to its sign (the sign comes from the improvement counter, which trace()
+    overrides, main.cpp:73-76), including rays through shared edges and vertices."""
+    import cgraytracing_amd as cg
+    tex = {"stone_small": lambda: scenes.stone_small_texture(True), "chessboard": lambda: scenes.chessboard_texture(True),
+           "procedural_stone": lambda: scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)}[which]()
+    objs = scenes.planes(tex)
+    o, d = _bump_floor_rays(tex, 40000 if which != "procedural_stone" else 16000, 3)
+    hw, lw, nw = BackendScene(orc, objs).intersect_batch(0, o, d)
+    sc = cg.Scene(objs)
+    hg, lg, ng = sc.intersect_rays(0, o, d)
+    sc.close()
+    assert np.array_equal(hg, hw)
+    m = hw != 0
+    assert np.array_equal(lg[m], lw[m])
+    same = np.all(ng[m] == nw[m], axis=1) | np.all(ng[m] == -nw[m], axis=1)
+    assert same.all()
+    bumped = m & (np.abs(nw[:, 1]) < 1.0)
+    print("%s: %d rays, %d hit the floor, %d of them on a tilted facet" % (which, len(o), m.sum(), bumped.sum()))
+    assert bumped.sum() > 1000
