@@ -177,7 +177,7 @@ typedef struct cgrt_photons {
     double alpha;      /* main.cpp:36: 0.7                                                                         */
     int64_t nphotons;  /* photons in total (reference: num_photon * num_threads = 20 480 000, main.cpp:223-224)     */
     int32_t hashsize;  /* main.cpp:184: 1000001 (bucket collisions are part of the semantics, hash.h:32-37)         */
-    int32_t batch;     /* photons traced per batch (0 = default 262144); does not change the result                */
+    int32_t batch;     /* photons traced per batch (0 = default 1048576); does not change the result               */
     uint64_t seed;
 } cgrt_photons;
 
