@@ -186,6 +186,185 @@ void HostTree::build() {
     b.ids.resize(n);
     for (size_t i = 0; i < n; i++) b.ids[i] = (int32_t)i;
     b.emit(0, n, 0);
+    build_bvh();
+}
+
+// ---- traversal hierarchy over the reference's leaves ---------------------------------------------------------------
+// What the reference's tree contributes to the RESULT is its leaves: which triangles share a leaf and in which order
+// (quirk Q5), and the order of the leaves themselves (ties between leaves, objects.h:297).  The inner nodes only decide
+// which leaves a ray reaches, and any set of boxes that contains every leaf a ray can hit serves (DESIGN.md section
+// 4.2).  The reference's inner nodes are poor at that job: object-median splits on the triangles' MAXIMUM coordinate,
+// heavily overlapping, and visited in an order unrelated to the ray.  So the device traverses a binned-SAH hierarchy
+// over the same leaves.  It stays stackless (preorder + skip links, like the reference-order form) and still visits
+// children front to back, because it is laid out eight times, once per octant of ray directions, each time with the
+// children of every node ordered near-to-far along that node's split axis -- 32 bytes per node and octant.
+namespace {
+struct BvhItem {
+    double lo[3], hi[3];
+    int32_t leafref;  // NodeRec::leaf encoding of the reference leaf
+    int32_t weight;   // triangles in it
+};
+struct BvhTmp {
+    double lo[3], hi[3];
+    int32_t left = -1, right = -1, axis = 0, leafref = -1;
+    bool left_is_lower = true;
+};
+struct BvhBuilder {
+    std::vector<BvhItem> items;
+    std::vector<int32_t> idx;
+    std::vector<BvhTmp> nodes;
+
+    static double half_area(const double *lo, const double *hi) {
+        const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    }
+    int32_t build(size_t b, size_t e, int depth) {
+        BvhTmp nd;
+        for (int k = 0; k < 3; k++) { nd.lo[k] = kInf; nd.hi[k] = -kInf; }
+        double clo[3] = {kInf, kInf, kInf}, chi[3] = {-kInf, -kInf, -kInf};
+        for (size_t i = b; i < e; i++) {
+            const BvhItem &it = items[(size_t)idx[i]];
+            for (int k = 0; k < 3; k++) {
+                nd.lo[k] = std::min(nd.lo[k], it.lo[k]);
+                nd.hi[k] = std::max(nd.hi[k], it.hi[k]);
+                const double c = 0.5 * (it.lo[k] + it.hi[k]);
+                clo[k] = std::min(clo[k], c);
+                chi[k] = std::max(chi[k], c);
+            }
+        }
+        const int32_t me = (int32_t)nodes.size();
+        nodes.push_back(nd);
+        if (e - b == 1) {
+            nodes[(size_t)me].leafref = items[(size_t)idx[b]].leafref;
+            return me;
+        }
+        // binned SAH over the three axes (16 bins on the centroid range); cost = area * triangles
+        constexpr int NB = 16;
+        int best_axis = -1, best_bin = -1;
+        double best_cost = 1e300;
+        for (int ax = 0; ax < 3 && depth < 48; ax++) {
+            const double ext = chi[ax] - clo[ax];
+            if (!(ext > 0)) continue;
+            double blo[NB][3], bhi[NB][3];
+            int64_t bw[NB];
+            for (int q = 0; q < NB; q++) {
+                bw[q] = 0;
+                for (int k = 0; k < 3; k++) { blo[q][k] = kInf; bhi[q][k] = -kInf; }
+            }
+            for (size_t i = b; i < e; i++) {
+                const BvhItem &it = items[(size_t)idx[i]];
+                int q = (int)((0.5 * (it.lo[ax] + it.hi[ax]) - clo[ax]) / ext * NB);
+                q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                bw[q] += it.weight;
+                for (int k = 0; k < 3; k++) {
+                    blo[q][k] = std::min(blo[q][k], it.lo[k]);
+                    bhi[q][k] = std::max(bhi[q][k], it.hi[k]);
+                }
+            }
+            double rlo[NB][3], rhi[NB][3];
+            int64_t rw[NB];
+            double alo[3] = {kInf, kInf, kInf}, ahi[3] = {-kInf, -kInf, -kInf};
+            int64_t aw = 0;
+            for (int q = NB - 1; q >= 1; q--) {  // suffix unions: bins q..NB-1
+                aw += bw[q];
+                for (int k = 0; k < 3; k++) { alo[k] = std::min(alo[k], blo[q][k]); ahi[k] = std::max(ahi[k], bhi[q][k]); }
+                rw[q] = aw;
+                for (int k = 0; k < 3; k++) { rlo[q][k] = alo[k]; rhi[q][k] = ahi[k]; }
+            }
+            double llo[3] = {kInf, kInf, kInf}, lhi[3] = {-kInf, -kInf, -kInf};
+            int64_t lw = 0;
+            for (int q = 0; q + 1 < NB; q++) {  // split after bin q
+                lw += bw[q];
+                for (int k = 0; k < 3; k++) { llo[k] = std::min(llo[k], blo[q][k]); lhi[k] = std::max(lhi[k], bhi[q][k]); }
+                if (lw == 0 || rw[q + 1] == 0) continue;
+                const double cost = half_area(llo, lhi) * (double)lw + half_area(rlo[q + 1], rhi[q + 1]) * (double)rw[q + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = q; }
+            }
+        }
+        size_t mid;
+        int axis;
+        if (best_axis >= 0) {
+            axis = best_axis;
+            const double ext = chi[axis] - clo[axis], c0 = clo[axis];
+            const int bin = best_bin;
+            auto it = std::partition(idx.begin() + (long)b, idx.begin() + (long)e, [&](int32_t id) {
+                const BvhItem &t = items[(size_t)id];
+                int q = (int)((0.5 * (t.lo[axis] + t.hi[axis]) - c0) / ext * NB);
+                q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                return q <= bin;
+            });
+            mid = (size_t)(it - idx.begin());
+        } else {  // coincident centroids or a very deep branch: object median on the widest axis
+            axis = 0;
+            for (int k = 1; k < 3; k++)
+                if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+            mid = b + (e - b) / 2;
+            std::nth_element(idx.begin() + (long)b, idx.begin() + (long)mid, idx.begin() + (long)e, [&](int32_t p, int32_t q) {
+                const BvhItem &P = items[(size_t)p], &Q = items[(size_t)q];
+                const double cp = P.lo[axis] + P.hi[axis], cq = Q.lo[axis] + Q.hi[axis];
+                return cp < cq || (cp == cq && p < q);
+            });
+        }
+        if (mid == b || mid == e) mid = b + (e - b) / 2;
+        const int32_t l = build(b, mid, depth + 1);
+        const int32_t r = build(mid, e, depth + 1);
+        BvhTmp &m = nodes[(size_t)me];
+        m.left = l;
+        m.right = r;
+        m.axis = axis;
+        const BvhTmp &L = nodes[(size_t)l], &R = nodes[(size_t)r];
+        m.left_is_lower = (L.lo[axis] + L.hi[axis]) <= (R.lo[axis] + R.hi[axis]);
+        return me;
+    }
+    void emit(int32_t n, int oct, std::vector<NodeRec> &out) const {
+        const BvhTmp &t = nodes[(size_t)n];
+        const size_t me = out.size();
+        NodeRec nr;
+        for (int k = 0; k < 3; k++) {
+            nr.lo[k] = round_down(t.lo[k] - kBoxPad);
+            nr.hi[k] = round_up(t.hi[k] + kBoxPad);
+        }
+        nr.skip = 0;
+        nr.leaf = t.leafref;
+        out.push_back(nr);
+        if (t.leafref < 0) {
+            const bool positive = ((oct >> t.axis) & 1) == 0;  // octant bit set = direction component negative
+            const bool left_first = (positive == t.left_is_lower);
+            emit(left_first ? t.left : t.right, oct, out);
+            emit(left_first ? t.right : t.left, oct, out);
+        }
+        out[me].skip = (int32_t)(out.size() - base);
+    }
+    size_t base = 0;
+};
+}  // namespace
+
+void HostTree::build_bvh() {
+    bvh.clear();
+    bvh_nodes = 0;
+    BvhBuilder B;
+    for (size_t n = 0; n < nodes.size(); n++)
+        if (nodes[n].leaf >= 0 && (nodes[n].leaf & 15) > 0) {  // the reference's leaves, in their own order
+            BvhItem it;
+            for (int k = 0; k < 3; k++) {
+                it.lo[k] = bbox[6 * n + 2 * (size_t)k];
+                it.hi[k] = bbox[6 * n + 2 * (size_t)k + 1];
+            }
+            it.leafref = nodes[n].leaf;
+            it.weight = nodes[n].leaf & 15;
+            B.items.push_back(it);
+        }
+    if (B.items.empty()) return;
+    B.idx.resize(B.items.size());
+    for (size_t i = 0; i < B.idx.size(); i++) B.idx[i] = (int32_t)i;
+    B.nodes.reserve(2 * B.items.size());
+    B.build(0, B.items.size(), 0);
+    bvh_nodes = (int32_t)B.nodes.size();
+    bvh.reserve((size_t)bvh_nodes * 8);
+    for (int oct = 0; oct < 8; oct++) {
+        B.base = bvh.size();
+        B.emit(0, oct, bvh);
+    }
 }
 
 // Grid-ordered view of a bump floor's triangles (call after build()).
@@ -194,12 +373,10 @@ void HostTree::build_hfield(int nx, int nz, double x0, double z0, double hx, dou
     if (nx < 1 || nz < 1 || ntri != (size_t)nx * nz * 2 || tris.size() != ntri) return;
     std::vector<int32_t> pos(ntri), leaf_of(ntri);
     for (size_t k = 0; k < ntri; k++) pos[(size_t)leaf_ids[k]] = (int32_t)k;
-    int32_t seq = 0;
     for (const NodeRec &nd : nodes)
-        if (nd.leaf >= 0) {
+        if (nd.leaf >= 0) {  // a leaf is identified by its first triangle's index, which grows with the leaf sequence
             const int32_t first = nd.leaf >> 4, cnt = nd.leaf & 15;
-            for (int32_t k = first; k < first + cnt; k++) leaf_of[(size_t)k] = seq;
-            seq++;
+            for (int32_t k = first; k < first + cnt; k++) leaf_of[(size_t)k] = first;
         }
     hcells.resize((size_t)nx * nz);
     double ylo = kInf, yhi = -kInf;

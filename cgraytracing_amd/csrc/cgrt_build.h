@@ -17,9 +17,16 @@ struct HostTree {
     std::vector<int32_t> node_lr_size;  // left, right, count
     std::vector<double> bbox;           // xmin,xmax,ymin,ymax,zmin,zmax (unpadded)
     std::vector<int32_t> leaf_ids;      // triangle ids of leaves, node order
-    // device view
+    // device view: the reference's leaves (tris, in leaf order) and two hierarchies over them --
+    // `nodes`: the reference's own tree in preorder with skip links;
+    // `bvh`  : a surface-area-heuristic hierarchy over the SAME leaves, stored once per ray-direction octant
+    //          (8 x bvh_nodes records, each a preorder with skip links whose children are ordered near-to-far
+    //          for rays of that octant), see build_bvh()
     std::vector<NodeRec> nodes;
     std::vector<TriRec> tris;
+    std::vector<NodeRec> bvh;
+    int32_t bvh_nodes = 0;
+    void build_bvh();
     // bump floors only: the same triangles in grid order (construction order is cell-major: quad (i,j) = triangles
     // 2*(i*nx+j) and +1), see HCellRec
     bool is_hfield = false;

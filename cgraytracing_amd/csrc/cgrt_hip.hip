@@ -144,6 +144,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
     r.len = kInf;
     r.tri = -1;
     r.counter = 0;
+    int r_leaf = -1;  // first triangle index of the leaf holding r.tri (grows with the reference's leaf sequence)
     int i = 0;
     // "while-while" traversal: every lane first walks inner nodes until it stands on a leaf its ray touches
     // (or runs out of nodes); only then does the wave scan leaves, so the ~800-instruction leaf scan runs once
@@ -214,10 +215,13 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             e2 = ne2;
         }
         if (leaf_cnt > 0) {
-            // objects.h:295-313: the left result survives only if strictly nearer => later leaf wins ties
-            if (r.counter == 0 || !(r.len < leaf_len)) {
+            // objects.h:295-313: the left result survives only if strictly nearer => the LATER leaf of the reference's
+            // sequence wins ties.  Spelled out on the leaf's position, because the hierarchy above the leaves need not
+            // visit them in the reference's order.
+            if (r.counter == 0 || leaf_len < r.len || (leaf_len == r.len && leaf_begin > r_leaf)) {
                 r.len = leaf_len;
                 r.tri = leaf_tri;
+                r_leaf = leaf_begin;
             }
             r.counter += leaf_cnt;
             if (PRUNE && r.len < bound) bound = r.len;
@@ -747,7 +751,10 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
         return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, o, d, inv, bound, n_node, n_tri);
     }
     const bool cached = aux.lnodes != nullptr && tr == sc.cached_tree;
-    const NodeRec *nodes = sc.nodes + T.node_begin;
+    // the copy of the hierarchy whose children are ordered near-to-far for this ray's direction octant (only worth a
+    // per-lane base address where order matters, i.e. for the pruned traversal)
+    const int oct = (T.noct == 8 && opaque) ? ((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) : 0;
+    const NodeRec *nodes = sc.nodes + T.node_begin + (size_t)oct * (size_t)T.nnodes;
     const TriRec *tris = sc.tris + T.tri_begin;
     if (opaque) {
         if (cached) return tree_intersect<STATS, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
@@ -1307,10 +1314,14 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         TreeRec tr;
         tr.node_begin = (int64_t)nodes.size();
         tr.tri_begin = (int64_t)tris.size();
-        tr.nnodes = (int32_t)t.nodes.size();
+        // CGRT_TREE=ref (measurement aid): traverse the reference's own inner nodes instead of the SAH hierarchy
+        const char *tree_env = std::getenv("CGRT_TREE");
+        const bool ref_order = tree_env && std::strcmp(tree_env, "ref") == 0;
+        const std::vector<NodeRec> &dev_nodes = ref_order ? t.nodes : t.bvh;
+        tr.nnodes = ref_order ? (int32_t)t.nodes.size() : t.bvh_nodes;
+        tr.noct = ref_order ? 1 : 8;
         tr.ntris = (int32_t)t.tris.size();
         tr.hfield = -1;
-        tr.pad = 0;
         if (t.is_hfield) {
             HFieldRec hf = t.hfield;
             hf.cell_begin = (int64_t)hcells.size();
@@ -1318,7 +1329,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
             hfields.push_back(hf);
             hcells.insert(hcells.end(), t.hcells.begin(), t.hcells.end());
         }
-        nodes.insert(nodes.end(), t.nodes.begin(), t.nodes.end());
+        nodes.insert(nodes.end(), dev_nodes.begin(), dev_nodes.end());
         tris.insert(tris.end(), t.tris.begin(), t.tris.end());
         trees.push_back(tr);
     }
@@ -1405,9 +1416,27 @@ int cgrt_scene_get_stats(const cgrt_scene *s, cgrt_scene_stats *out) {
 int cgrt_scene_tree_sizes(const cgrt_scene *s, int t, int32_t *nnodes, int32_t *nleaftris, int32_t *ntris) {
     if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
     const HostTree &T = s->host.trees[t];
-    if (nnodes) *nnodes = (int32_t)T.nodes.size();
+    if (nnodes) *nnodes = (int32_t)T.nodes.size();  // the reference's tree (fingerprints); the device hierarchy is T.bvh
     if (nleaftris) *nleaftris = (int32_t)T.leaf_ids.size();
     if (ntris) *ntris = (int32_t)(T.tri9.size() / 9);
+    return CGRT_OK;
+}
+int cgrt_scene_bvh_dump(const cgrt_scene *s, int t, int32_t *nnodes, float *box6, int32_t *skip_leaf2) {
+    if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
+    const HostTree &T = s->host.trees[t];
+    if (nnodes) *nnodes = T.bvh_nodes;
+    for (size_t i = 0; i < T.bvh.size(); i++) {
+        if (box6) {
+            for (int k = 0; k < 3; k++) {
+                box6[6 * i + k] = T.bvh[i].lo[k];
+                box6[6 * i + 3 + k] = T.bvh[i].hi[k];
+            }
+        }
+        if (skip_leaf2) {
+            skip_leaf2[2 * i] = T.bvh[i].skip;
+            skip_leaf2[2 * i + 1] = T.bvh[i].leaf;
+        }
+    }
     return CGRT_OK;
 }
 int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int32_t *leaf_ids, double *bbox,

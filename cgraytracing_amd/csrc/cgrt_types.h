@@ -62,7 +62,8 @@ struct TreeRec {
     int32_t nnodes;
     int32_t ntris;
     int32_t hfield;      // bump floors: index into hfields[] (the same triangles as a regular grid), else -1
-    int32_t pad;
+    int32_t noct;        // copies of the node array at node_begin, nnodes apart: 8 (one per ray-direction octant,
+                         // children near-to-far) for the SAH hierarchy, 1 for the reference-order tree
 };
 
 // A bump-mapped floor's displacement mesh (objects.h:482-503) is a height field over a regular x-z grid: one quad per
@@ -73,7 +74,7 @@ struct TreeRec {
 struct HCellRec {
     TriRec t[2];
     int32_t k[2];     // index in the tree's leaf-ordered tris[] (relative to tri_begin)
-    int32_t leaf[2];  // sequence number of the leaf holding it
+    int32_t leaf[2];  // first triangle index of the leaf holding it (grows with the leaf's sequence number)
 };
 static_assert(sizeof(HCellRec) == 160, "HCellRec layout");
 struct HFieldRec {

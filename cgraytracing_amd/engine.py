@@ -96,6 +96,16 @@ class Scene:
                                            tris.ctypes.data))
         return nodes, leaf, bbox, tris
 
+    def bvh_dump(self, t=0):
+        """The hierarchy the device traverses (cgrt_scene_bvh_dump): boxes [8, n, 6] float32, skip [8, n], leaf [8, n]."""
+        nn = C.c_int32()
+        check(self._L.cgrt_scene_bvh_dump(self._h, t, C.byref(nn), None, None))
+        n = nn.value
+        box = np.zeros((8, n, 6), np.float32)
+        sl = np.zeros((8, n, 2), np.int32)
+        check(self._L.cgrt_scene_bvh_dump(self._h, t, C.byref(nn), box.ctypes.data, sl.ctypes.data))
+        return box, sl[:, :, 0].copy(), sl[:, :, 1].copy()
+
     # ---- the hot path ----
     def _structs(self, camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
                  spp_total, flags):

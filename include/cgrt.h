@@ -140,6 +140,13 @@ int cgrt_scene_tree_sizes(const cgrt_scene *s, int t, int32_t *nnodes, int32_t *
 int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int32_t *leaf_ids, double *bbox,
                          double *tri9);
 
+/* The hierarchy the device actually traverses over the reference's leaves (a binned-SAH tree stored once per ray-direction
+ * octant, children near-to-far): *nnodes = nodes per octant; box6 = 8*nnodes x {lo(3), hi(3)}
+ * (grown and rounded outward to fp32); skip_leaf2 = 8*nnodes x {skip link relative to the octant's first node,
+ * leaf = -1 for inner nodes else (first triangle in leaf order << 4) | count}.  Either array may be NULL
+ * (call once with both NULL to size them). */
+int cgrt_scene_bvh_dump(const cgrt_scene *s, int tree, int32_t *nnodes, float *box6, int32_t *skip_leaf2);
+
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Renders grid->rows rows: for every pixel and sample it runs the reference's trace(flag=true) recursion
  * (iteratively) and writes

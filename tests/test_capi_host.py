@@ -206,3 +206,59 @@ def test_write_png_errors(tmp_path):
     assert L.cgrt_write_png(None, 2, 2, buf.ctypes.data) == -1
     assert L.cgrt_write_png(os.fsencode(str(tmp_path / "no_such_dir" / "x.png")), 2, 2, buf.ctypes.data) == -2
     assert b"cannot open" in L.cgrt_last_error()
+
+
+def _check_hierarchy(sc, t, tri9_leaf_order):
+    """Structural properties the device traversal relies on, per octant copy: preorder with
+    consistent skip links; every reference leaf present exactly once; each node's box contains its children's boxes and
+    every triangle below it (un-grown); the two children of a node are ordered near-to-far for the octant."""
+    nodes, leaf_ids, bbox, tris = sc.tree_dump(t)
+    ref_leaves = sorted(((int(nodes[i, 2]), i) for i in range(len(nodes)) if nodes[i, 0] < 0), key=lambda x: x[1])
+    box, skip, leaf = sc.bvh_dump(t)
+    n = box.shape[1]
+    assert n == 2 * len([1 for i in range(len(nodes)) if nodes[i, 0] < 0 and nodes[i, 2] > 0]) - 1
+    tri = tris[leaf_ids] if tri9_leaf_order is None else tri9_leaf_order
+    tlo = tri.reshape(-1, 3, 3).min(1)
+    thi = tri.reshape(-1, 3, 3).max(1)
+    want_leaves = None
+    for o in range(8):
+        sk, lf, bx = skip[o], leaf[o], box[o]
+        assert sk[0] == n
+        leaves = lf[lf >= 0]
+        got = sorted((int(v) >> 4, int(v) & 15) for v in leaves)
+        if want_leaves is None:
+            want_leaves = got
+            assert sum(c for _, c in got) == len(tri)
+            assert [f for f, _ in got] == list(np.cumsum([0] + [c for _, c in got[:-1]]))  # contiguous leaf ranges
+        assert got == want_leaves
+        sgn = np.array([-1.0 if (o >> k) & 1 else 1.0 for k in range(3)])
+        # walk: node i's subtree is [i, skip[i])
+        for i in range(n):
+            assert i < sk[i] <= n
+            if lf[i] >= 0:
+                assert sk[i] == i + 1
+                f, c = int(lf[i]) >> 4, int(lf[i]) & 15
+                assert (bx[i, :3] <= tlo[f:f + c].min(0)).all() and (bx[i, 3:] >= thi[f:f + c].max(0)).all()
+            else:
+                a, b = i + 1, sk[i + 1]
+                assert sk[b] == sk[i]  # exactly two children
+                for ch in (a, b):
+                    assert (bx[ch, :3] >= bx[i, :3]).all() and (bx[ch, 3:] <= bx[i, 3:]).all()
+                # near-to-far along SOME axis for this octant: the first child's centre does not lie behind the second's
+                ca, cb = bx[a, :3] + bx[a, 3:], bx[b, :3] + bx[b, 3:]
+                assert ((cb - ca) * sgn >= 0).any()
+
+
+def test_device_hierarchy_structure():
+    """Host build of the SAH hierarchy over the reference's leaves (no GPU): small authored mesh, the bunny, a bump floor."""
+    from cgraytracing_amd.engine import Scene
+    m = scenes.TriangleMesh(os.path.join(GOLD, "assets", "mesh_t1.txt"), 2.5, (-3.0, -6.0, 28.0), (0.6, 0.7, 0.9), 0.8, 0.5, 1)
+    sc = Scene([m], commit=False)
+    _check_hierarchy(sc, 0, None)
+    sc.close()
+    sc = Scene(scenes.scene_c3(True), commit=False)
+    _check_hierarchy(sc, 0, None)
+    sc.close()
+    sc = Scene(scenes.planes(scenes.stone_small_texture(True)), commit=False)
+    _check_hierarchy(sc, 0, None)
+    sc.close()
