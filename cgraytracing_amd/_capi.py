@@ -84,6 +84,7 @@ SIGNATURES = {
     "cgrt_photon_events": (C.c_int, [C.c_void_p, C.POINTER(Photons), C.c_int, C.c_int64, C.c_int32, C.c_void_p,
                                      C.c_void_p]),
     "cgrt_scene_bvh_dump": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
+    "cgrt_scene_bvh_order": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p]),
     "cgrt_lens_samples": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "cgrt_intersect_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

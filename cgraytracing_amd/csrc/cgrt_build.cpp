@@ -175,7 +175,7 @@ struct Scanner {
 
 }  // namespace
 
-void HostTree::build() {
+void HostTree::build(bool opaque, bool with_bvh) {
     nodes.clear();
     tris.clear();
     node_lr_size.clear();
@@ -186,7 +186,7 @@ void HostTree::build() {
     b.ids.resize(n);
     for (size_t i = 0; i < n; i++) b.ids[i] = (int32_t)i;
     b.emit(0, n, 0);
-    build_bvh();
+    if (with_bvh) build_bvh(opaque);
 }
 
 // ---- traversal hierarchy over the reference's leaves ---------------------------------------------------------------
@@ -213,6 +213,8 @@ struct BvhBuilder {
     std::vector<BvhItem> items;
     std::vector<int32_t> idx;
     std::vector<BvhTmp> nodes;
+    size_t max_leaf = 1;  // 1: one item (a reference leaf) per leaf, leafref = the item's; > 1: items are triangles and
+                          // a leaf is a run of idx, leafref = (first position << 4) | count
 
     static double half_area(const double *lo, const double *hi) {
         const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
@@ -234,8 +236,8 @@ struct BvhBuilder {
         }
         const int32_t me = (int32_t)nodes.size();
         nodes.push_back(nd);
-        if (e - b == 1) {
-            nodes[(size_t)me].leafref = items[(size_t)idx[b]].leafref;
+        if (e - b <= max_leaf) {
+            nodes[(size_t)me].leafref = max_leaf == 1 ? items[(size_t)idx[b]].leafref : (int32_t)((b << 4) | (e - b));
             return me;
         }
         // binned SAH over the three axes (16 bins on the centroid range); cost = area * triangles
@@ -339,21 +341,43 @@ struct BvhBuilder {
 };
 }  // namespace
 
-void HostTree::build_bvh() {
+void HostTree::build_bvh(bool opaque) {
     bvh.clear();
+    otris.clear();
     bvh_nodes = 0;
+    tri_level = opaque;
     BvhBuilder B;
-    for (size_t n = 0; n < nodes.size(); n++)
-        if (nodes[n].leaf >= 0 && (nodes[n].leaf & 15) > 0) {  // the reference's leaves, in their own order
+    std::vector<int32_t> leaf_first;  // tri_level: first leaf-order index of the reference leaf of triangle k
+    if (opaque) {
+        B.max_leaf = 4;
+        leaf_first.resize(tris.size());
+        for (const NodeRec &nd : nodes)
+            if (nd.leaf >= 0)
+                for (int32_t k = nd.leaf >> 4; k < (nd.leaf >> 4) + (nd.leaf & 15); k++) leaf_first[(size_t)k] = nd.leaf >> 4;
+        for (size_t k = 0; k < tris.size(); k++) {  // triangles in the reference's leaf order
+            const double *t = &tri9[9 * (size_t)leaf_ids[k]];
             BvhItem it;
-            for (int k = 0; k < 3; k++) {
-                it.lo[k] = bbox[6 * n + 2 * (size_t)k];
-                it.hi[k] = bbox[6 * n + 2 * (size_t)k + 1];
+            for (int c = 0; c < 3; c++) {
+                it.lo[c] = lo3(t[c], t[3 + c], t[6 + c]);
+                it.hi[c] = hi3(t[c], t[3 + c], t[6 + c]);
             }
-            it.leafref = nodes[n].leaf;
-            it.weight = nodes[n].leaf & 15;
+            it.leafref = -1;
+            it.weight = 1;
             B.items.push_back(it);
         }
+    } else {
+        for (size_t n = 0; n < nodes.size(); n++)
+            if (nodes[n].leaf >= 0 && (nodes[n].leaf & 15) > 0) {  // the reference's leaves, in their own order
+                BvhItem it;
+                for (int k = 0; k < 3; k++) {
+                    it.lo[k] = bbox[6 * n + 2 * (size_t)k];
+                    it.hi[k] = bbox[6 * n + 2 * (size_t)k + 1];
+                }
+                it.leafref = nodes[n].leaf;
+                it.weight = nodes[n].leaf & 15;
+                B.items.push_back(it);
+            }
+    }
     if (B.items.empty()) return;
     B.idx.resize(B.items.size());
     for (size_t i = 0; i < B.idx.size(); i++) B.idx[i] = (int32_t)i;
@@ -364,6 +388,15 @@ void HostTree::build_bvh() {
     for (int oct = 0; oct < 8; oct++) {
         B.base = bvh.size();
         B.emit(0, oct, bvh);
+    }
+    if (opaque) {  // triangle records in the hierarchy's own order, each with its rank for ties
+        otris.resize(tris.size());
+        for (size_t j = 0; j < otris.size(); j++) {
+            const int32_t k = B.idx[j];
+            otris[j].t = tris[(size_t)k];
+            otris[j].k = k;
+            otris[j].leaf = leaf_first[(size_t)k];
+        }
     }
 }
 
@@ -512,8 +545,9 @@ int HostScene::add_plane(const double p[3], const double n[3], const double sc[3
                 for (const double *v : {A, B, Cc}) tree.tri9.insert(tree.tri9.end(), v, v + 3);
                 for (const double *v : {D, B, Cc}) tree.tri9.insert(tree.tri9.end(), v, v + 3);
             }
-        tree.build();
+        tree.build(transp < kEps, false);
         tree.build_hfield(C / step - 1, R / step - 1, tx.p[0], tx.p[2], tx.lenx * step / C, tx.leny * step / R);
+        if (!(tree.is_hfield && transp < kEps)) tree.build_bvh(transp < kEps);  // an opaque floor is walked as a grid
         trees.push_back(std::move(tree));
         o.tree = (int)trees.size() - 1;
     }
@@ -528,7 +562,7 @@ int HostScene::add_mesh_triangles(const double *tri9, int ntri, const double sc[
     o.aux = type;
     HostTree tree;
     tree.tri9.assign(tri9, tri9 + (size_t)ntri * 9);
-    tree.build();  // objects.h:402
+    tree.build(transp < kEps);  // objects.h:402; an opaque owner gets the triangle-level hierarchy
     trees.push_back(std::move(tree));
     o.tree = (int)trees.size() - 1;
     objs.push_back(o);

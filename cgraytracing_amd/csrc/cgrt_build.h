@@ -26,13 +26,17 @@ struct HostTree {
     std::vector<TriRec> tris;
     std::vector<NodeRec> bvh;
     int32_t bvh_nodes = 0;
-    void build_bvh();
+    // opaque owner (transparency < eps): only the nearest hit matters, so the hierarchy goes down to small groups of
+    // TRIANGLES (<= 4) instead of stopping at the reference's leaves; its leaves index otris
+    bool tri_level = false;
+    std::vector<OTriRec> otris;
+    void build_bvh(bool opaque);
     // bump floors only: the same triangles in grid order (construction order is cell-major: quad (i,j) = triangles
     // 2*(i*nx+j) and +1), see HCellRec
     bool is_hfield = false;
     HFieldRec hfield{};
     std::vector<HCellRec> hcells;
-    void build();
+    void build(bool opaque = false, bool with_bvh = true);
     void build_hfield(int nx, int nz, double x0, double z0, double hx, double hz);
 };
 

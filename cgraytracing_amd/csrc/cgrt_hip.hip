@@ -136,10 +136,14 @@ struct TreeHit {
 // it -- can be skipped: a hit inside it would lose the strict `len < nearest` tests (objects.h:281,297;
 // main.cpp:57).  Entry distances come from the grown, outward-rounded boxes, so they never exceed the true
 // ones and a leaf holding a triangle that ties with the bound is still scanned: (len, triangle) stay exact.
-template <bool STATS, bool PRUNE>
+//
+// TRI (implies PRUNE): the hierarchy goes down to groups of <= 4 single triangles (`otris`, each carrying its place in
+// the reference's leaf order); with no leaf-wide scan order to rely on, every accepted hit is compared on
+// (len, reference leaf, index) directly -- the same winner as "first inside a leaf, last leaf across leaves".
+template <bool STATS, bool PRUNE, bool TRI = false>
 __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                   int nnodes, V3 o, V3 d, V3 inv, double bound, uint32_t &n_node,
-                                                  uint32_t &n_tri) {
+                                                  uint32_t &n_tri, const OTriRec *__restrict__ otris = nullptr) {
     TreeHit r;
     r.len = kInf;
     r.tri = -1;
@@ -182,6 +186,34 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             break;
         }
         if (leaf_cnt_tris < 0) break;  // no further leaf for this lane
+        if (TRI) {
+            const OTriRec *tp = otris + leaf_begin;
+            for (int k = 0; k < leaf_cnt_tris; k++) {
+                if (STATS) n_tri++;
+                const V3 pa = ld3(tp[k].t.pa), e1 = ld3(tp[k].t.e1), e2 = ld3(tp[k].t.e2);
+                const int2 rank = *reinterpret_cast<const int2 *>(&tp[k].k);  // k, leaf
+                const V3 s = pa - o;
+                const double det1 = det3(d, e1, e2);
+                const double det2 = det3(s, e1, e2);
+                const double det3_ = det3(d, s, e2);
+                const double det4 = det3(d, e1, s);
+                const double sg = det1 > 0.0 ? 1.0 : -1.0;
+                const double a1 = det1 * sg;
+                const bool ok = (det1 != 0.0) && (det2 * sg > 0.0) && (det3_ * sg >= 0.0) && (det4 * sg >= 0.0) &&
+                                ((det3_ + det4) * sg <= a1);
+                if (ok) {
+                    const double len = det2 / det1;
+                    if (len < r.len || (len == r.len && (rank.y > r_leaf || (rank.y == r_leaf && rank.x < r.tri)))) {
+                        r.len = len;
+                        r.tri = rank.x;
+                        r_leaf = rank.y;
+                        r.counter = 1;
+                    }
+                }
+            }
+            if (r.len < bound) bound = r.len;
+            continue;
+        }
         // leaf scan, objects.h:273-289
         double leaf_len = kInf;
         int leaf_tri = -1, leaf_cnt = 0;
@@ -757,6 +789,11 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     const NodeRec *nodes = sc.nodes + T.node_begin + (size_t)oct * (size_t)T.nnodes;
     const TriRec *tris = sc.tris + T.tri_begin;
     if (opaque) {
+        if (T.tri_level) {
+            const OTriRec *ot = sc.otris + T.otri_begin;
+            if (cached) return tree_intersect<STATS, true, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, ot);
+            return tree_intersect<STATS, true, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, ot);
+        }
         if (cached) return tree_intersect<STATS, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
         return tree_intersect<STATS, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
     }
@@ -1310,6 +1347,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     std::vector<TreeRec> trees;
     std::vector<HFieldRec> hfields;
     std::vector<HCellRec> hcells;
+    std::vector<OTriRec> otris;
     for (auto &t : H.trees) {
         TreeRec tr;
         tr.node_begin = (int64_t)nodes.size();
@@ -1320,6 +1358,10 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         const std::vector<NodeRec> &dev_nodes = ref_order ? t.nodes : t.bvh;
         tr.nnodes = ref_order ? (int32_t)t.nodes.size() : t.bvh_nodes;
         tr.noct = ref_order ? 1 : 8;
+        tr.tri_level = (!ref_order && t.tri_level) ? 1 : 0;
+        tr.pad = 0;
+        tr.otri_begin = (int64_t)otris.size();
+        if (tr.tri_level) otris.insert(otris.end(), t.otris.begin(), t.otris.end());
         tr.ntris = (int32_t)t.tris.size();
         tr.hfield = -1;
         if (t.is_hfield) {
@@ -1362,6 +1404,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     if ((rc = upload(s, H.beziers, &d.beziers))) return rc;
     if ((rc = upload(s, hfields, &d.hfields))) return rc;
     if ((rc = upload(s, hcells, &d.hcells))) return rc;
+    if ((rc = upload(s, otris, &d.otris))) return rc;
     d.n_objs = (int32_t)H.objs.size();
     d.n_trees = (int32_t)trees.size();
     d.n_texs = (int32_t)texs.size();
@@ -1437,6 +1480,14 @@ int cgrt_scene_bvh_dump(const cgrt_scene *s, int t, int32_t *nnodes, float *box6
             skip_leaf2[2 * i + 1] = T.bvh[i].leaf;
         }
     }
+    return CGRT_OK;
+}
+int cgrt_scene_bvh_order(const cgrt_scene *s, int t, int32_t *tri_level, int32_t *order) {
+    if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
+    const HostTree &T = s->host.trees[t];
+    if (tri_level) *tri_level = T.tri_level ? 1 : 0;
+    if (order)
+        for (size_t j = 0; j < T.otris.size(); j++) order[j] = T.otris[j].k;
     return CGRT_OK;
 }
 int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int32_t *leaf_ids, double *bbox,

@@ -56,14 +56,27 @@ struct TriRec {
     double e2[3];
 };
 
+// Opaque meshes: a triangle of the triangle-level hierarchy -- the same TriRec as in tris[], plus its place in the
+// reference's leaf order, which decides exact ties (k: index in leaf order; leaf: first index of its reference leaf).
+struct OTriRec {
+    TriRec t;
+    int32_t k;
+    int32_t leaf;
+};
+static_assert(sizeof(OTriRec) == 80, "OTriRec layout");
+
 struct TreeRec {
     int64_t node_begin;  // into nodes[]
     int64_t tri_begin;   // into tris[]
+    int64_t otri_begin;  // tri_level only: into otris[]
     int32_t nnodes;
     int32_t ntris;
     int32_t hfield;      // bump floors: index into hfields[] (the same triangles as a regular grid), else -1
     int32_t noct;        // copies of the node array at node_begin, nnodes apart: 8 (one per ray-direction octant,
                          // children near-to-far) for the SAH hierarchy, 1 for the reference-order tree
+    int32_t tri_level;   // 1: the hierarchy is over single triangles (opaque owner), leaves index otris[]; 0: over the
+                         // reference's leaves, leaves index tris[]
+    int32_t pad;
 };
 
 // A bump-mapped floor's displacement mesh (objects.h:482-503) is a height field over a regular x-z grid: one quad per
@@ -113,6 +126,7 @@ struct DeviceScene {
     const BezierRec *beziers;
     const HFieldRec *hfields;
     const HCellRec *hcells;
+    const OTriRec *otris;
     int32_t n_objs, n_trees, n_texs, n_beziers;
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
     int32_t has_bezier;

@@ -106,6 +106,15 @@ class Scene:
         check(self._L.cgrt_scene_bvh_dump(self._h, t, C.byref(nn), box.ctypes.data, sl.ctypes.data))
         return box, sl[:, :, 0].copy(), sl[:, :, 1].copy()
 
+    def bvh_order(self, t=0):
+        """(tri_level, order): see cgrt_scene_bvh_order."""
+        nn, nl, nt = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self._L.cgrt_scene_tree_sizes(self._h, t, C.byref(nn), C.byref(nl), C.byref(nt)))
+        lvl = C.c_int32()
+        order = np.zeros(max(nt.value, 1), np.int32)
+        check(self._L.cgrt_scene_bvh_order(self._h, t, C.byref(lvl), order.ctypes.data))
+        return bool(lvl.value), order[: nt.value]
+
     # ---- the hot path ----
     def _structs(self, camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
                  spp_total, flags):

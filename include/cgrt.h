@@ -146,6 +146,10 @@ int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int3
  * leaf = -1 for inner nodes else (first triangle in leaf order << 4) | count}.  Either array may be NULL
  * (call once with both NULL to size them). */
 int cgrt_scene_bvh_dump(const cgrt_scene *s, int tree, int32_t *nnodes, float *box6, int32_t *skip_leaf2);
+/* *tri_level = 1 when the owner is opaque and the hierarchy goes down to single triangles: leaf references of
+ * cgrt_scene_bvh_dump then index the hierarchy's own triangle order, and order[j] (ntris entries, may be NULL) is the
+ * leaf-order index of the triangle at position j; 0: leaf references index the reference's leaf order directly. */
+int cgrt_scene_bvh_order(const cgrt_scene *s, int tree, int32_t *tri_level, int32_t *order);
 
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Renders grid->rows rows: for every pixel and sample it runs the reference's trace(flag=true) recursion
