@@ -447,15 +447,36 @@ __device__ __forceinline__ double bern(int n, int i, double t) {
 __device__ __forceinline__ double dbern(int n, int i, double t) {
     return bern(n - 1, i - 1, t) * (double)i - bern(n - 1, i, t) * (double)(n - i);
 }
-__device__ __forceinline__ V3 bez_value(const BezierRec &b, double u) {  // valueP, bezier.h:127-134
+// valueP / gradP (bezier.h:127-142).  With the number of control points a compile-time constant the loops unroll, the
+// integer powers of u and 1-u -- which the reference recomputes inside every Bernstein term -- are computed once, and
+// the binomials fold; the arithmetic per term is unchanged (same products in the same order), so are the values.
+template <int N>
+__device__ __forceinline__ V3 bez_value_n(const BezierRec &b, double u) {
     V3 r = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; i++) r = r + ld3(b.cp[i]) * bern(N - 1, i, u);
+    return r;
+}
+template <int N>
+__device__ __forceinline__ V3 bez_grad_n(const BezierRec &b, double u) {
+    V3 r = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; i++) r = r + ld3(b.cp[i]) * dbern(N - 1, i, u);
+    return r;
+}
+__device__ __forceinline__ V3 bez_value(const BezierRec &b, double u) {
     const int n = b.ncp;
+    if (n == 4) return bez_value_n<4>(b, u);  // the reference's vase (main.cpp:371-376)
+    if (n == 3) return bez_value_n<3>(b, u);
+    V3 r = mk(0, 0, 0);
     for (int i = 0; i < n; i++) r = r + ld3(b.cp[i]) * bern(n - 1, i, u);
     return r;
 }
-__device__ __forceinline__ V3 bez_grad(const BezierRec &b, double u) {  // gradP, bezier.h:135-142
-    V3 r = mk(0, 0, 0);
+__device__ __forceinline__ V3 bez_grad(const BezierRec &b, double u) {
     const int n = b.ncp;
+    if (n == 4) return bez_grad_n<4>(b, u);
+    if (n == 3) return bez_grad_n<3>(b, u);
+    V3 r = mk(0, 0, 0);
     for (int i = 0; i < n; i++) r = r + ld3(b.cp[i]) * dbern(n - 1, i, u);
     return r;
 }
