@@ -66,6 +66,48 @@ def cpu_baseline_mt(sample_spp):
             "sample": "%dx%d spp=%d, OpenMP over rows" % (W, H, sample_spp)}
 
 
+def other_configs(dev_index):
+    """Secondary, single-frame measurements on this GPU (N = 1 only; a few seconds in total): BASELINE.json configs[2]
+    and configs[3] at full size on one GPU, and the reference's committed main() configuration end to end (eye pass,
+    20.48 M photons, gather, tone map).  Reported beside the headline value, never part of it."""
+    import torch
+
+    import cgraytracing_amd as cg
+    import scenes
+
+    out = {}
+
+    def eye(name, objs, cam, w, h, spp):
+        sc = cg.Scene(objs, device=dev_index)
+        buf = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:%d" % dev_index)
+        cnt = torch.zeros(8, dtype=torch.int64, device=buf.device)
+        sc.trace_grid(w, h, 1, cam, DEPTH, SEED, out=buf, nhit=False, counters=cnt)  # warm-up: one sample per pixel
+        torch.cuda.synchronize()
+        cnt.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sc.trace_grid(w, h, spp, cam, DEPTH, SEED, out=buf, nhit=False, counters=cnt)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        rays = int(cnt[0].item())
+        sc.close()
+        out[name] = {"ms_per_frame": round(ms, 2), "rays": rays, "mrays_per_s": round(rays / ms / 1e3, 1)}
+
+    eye("C3 2048x2048 spp64 glass bunny + ChessBoard floor, thin lens", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 64)
+    eye("C4 4096x4096 spp256 dragon (all rows on one GPU), thin lens", scenes.scene_dragon(), scenes.cam_dof(), 4096, 4096, 256)
+    tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    objs = scenes.planes(tex) + [scenes.TriangleMesh.from_triangles(scenes.dragon_tris(), (0.25, 0.25, 0.5), 0.0, 0.0, 1)]
+    sc = cg.Scene(objs, device=dev_index)
+    sc.ppm_render(64, 48, 1, scenes.cam_pinhole(), 5, SEED, nphotons=1000)
+    r = sc.ppm_render(1024, 768, 1, scenes.cam_pinhole(), 5, SEED, nphotons=20480000)
+    sc.close()
+    out["reference main() configuration: 1024x768 spp1, bump floor + dragon, 20 480 000 photons (rows f1/f2)"] = {
+        "ms_total": round(sum(r["ms"].values()), 1), "stage_ms": {k: round(v, 2) for k, v in r["ms"].items()},
+        "photons_per_s": round(20480000 / (r["ms"]["photons"] / 1e3)), "photon_events": r["n_events"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +116,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--check", action="store_true", help="verify a crop of the frame against the oracle")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-frame measurements")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +263,11 @@ def main():
                 line["cpu_baseline_all_cores"] = cpu_baseline_mt(args.cpu_spp)
             except Exception as e:  # pragma: no cover
                 line["cpu_baseline_all_cores"] = {"error": str(e)}
+        if n == 1 and not args.no_other_configs:
+            try:
+                line["other_configs"] = other_configs(dev_index)
+            except Exception as e:  # pragma: no cover - never let a secondary measurement lose the headline line
+                line["other_configs"] = {"error": repr(e)}
         if args.check and n == 1:
             from backends import Backend, BackendScene, to_acc32
             import numpy as np
