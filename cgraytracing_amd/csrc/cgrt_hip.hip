@@ -1604,6 +1604,17 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
 
 }  // extern "C"
 
+struct DevBuf {  // RAII for device temporaries: freed on every return path
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    void *release() { void *q = p; p = nullptr; return q; }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
 // Eye pass with Hitpoint capture into a device buffer of `cap` records (10 doubles each); *count = hitpoints produced.
 // *d_rec_out is hipMalloc'ed here (caller frees) unless cap == 0.
 static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, uint64_t cap,
@@ -1618,12 +1629,13 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     for (int k = 0; k < 3; k++) g.cam[k] = cam->cam[k];
     g.half_width = cam->half_width; g.focus_plane = cam->focus_plane; g.lens_radius = cam->lens_radius;
     const size_t npx = (size_t)grid->rows * grid->width;
-    float *d_rgb = nullptr;
-    double *d_rec = nullptr;
-    unsigned long long *d_cnt = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_rgb, npx * 3 * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&d_rec, (cap ? cap : 1) * 10 * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
+    DevBuf b_rgb, b_rec, b_cnt;
+    HIP_TRY(b_rgb.alloc(npx * 3 * sizeof(float)));
+    HIP_TRY(b_rec.alloc((cap ? cap : 1) * 10 * sizeof(double)));
+    HIP_TRY(b_cnt.alloc(sizeof(unsigned long long)));
+    float *d_rgb = b_rgb.as<float>();
+    double *d_rec = b_rec.as<double>();
+    unsigned long long *d_cnt = b_cnt.as<unsigned long long>();
     HIP_TRY(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
     const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
     const dim3 grid_dim((unsigned)(tiles_x * tiles_y)), block(kThreads);
@@ -1645,8 +1657,7 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     if (rc == CGRT_OK && hipMemcpy(&n, d_cnt, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(CGRT_ERR_DEVICE, "hitpoint count copy");
     *count = n;
-    (void)hipFree(d_rgb); (void)hipFree(d_cnt);
-    if (rc == CGRT_OK && cap && d_rec_out) *d_rec_out = d_rec; else (void)hipFree(d_rec);
+    if (rc == CGRT_OK && cap && d_rec_out) *d_rec_out = reinterpret_cast<double *>(b_rec.release());
     return rc;
 }
 
@@ -1678,12 +1689,13 @@ int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt
     if (!rgb) return fail(CGRT_ERR_INVALID, "null rgb");
     HIP_TRY(hipSetDevice(s->device));
     const size_t npx = (size_t)grid->rows * grid->width;
-    float *d_rgb = nullptr;
-    uint32_t *d_nhit = nullptr;
-    uint64_t *d_cnt = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_rgb, npx * 3 * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&d_nhit, npx * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&d_cnt, CGRT_NCOUNTERS * sizeof(uint64_t)));
+    DevBuf b_rgb, b_nhit, b_cnt;
+    HIP_TRY(b_rgb.alloc(npx * 3 * sizeof(float)));
+    HIP_TRY(b_nhit.alloc(npx * sizeof(uint32_t)));
+    HIP_TRY(b_cnt.alloc(CGRT_NCOUNTERS * sizeof(uint64_t)));
+    float *d_rgb = b_rgb.as<float>();
+    uint32_t *d_nhit = b_nhit.as<uint32_t>();
+    uint64_t *d_cnt = b_cnt.as<uint64_t>();
     HIP_TRY(hipMemset(d_rgb, 0, npx * 3 * sizeof(float)));
     HIP_TRY(hipMemset(d_nhit, 0, npx * sizeof(uint32_t)));
     HIP_TRY(hipMemset(d_cnt, 0, CGRT_NCOUNTERS * sizeof(uint64_t)));
@@ -1697,9 +1709,6 @@ int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt
         if (nhit) HIP_TRY(hipMemcpy(nhit, d_nhit, npx * sizeof(uint32_t), hipMemcpyDeviceToHost));
         if (counters) HIP_TRY(hipMemcpy(counters, d_cnt, CGRT_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
-    (void)hipFree(d_rgb);
-    (void)hipFree(d_nhit);
-    (void)hipFree(d_cnt);
     return rc;
 }
 
@@ -1710,18 +1719,20 @@ int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const 
         return fail(CGRT_ERR_INVALID, "bad argument");
     if (n == 0) return CGRT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    double *d_o = nullptr, *d_d = nullptr, *d_len = nullptr, *d_n = nullptr;
-    int32_t *d_hit = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_o, (size_t)n * 24));
-    HIP_TRY(hipMalloc((void **)&d_d, (size_t)n * 24));
-    HIP_TRY(hipMalloc((void **)&d_len, (size_t)n * 8));
-    HIP_TRY(hipMalloc((void **)&d_n, (size_t)n * 24));
-    HIP_TRY(hipMalloc((void **)&d_hit, (size_t)n * 4));
+    DevBuf b_o, b_d, b_len, b_n, b_hit, b_keys;
+    HIP_TRY(b_o.alloc((size_t)n * 24));
+    HIP_TRY(b_d.alloc((size_t)n * 24));
+    HIP_TRY(b_len.alloc((size_t)n * 8));
+    HIP_TRY(b_n.alloc((size_t)n * 24));
+    HIP_TRY(b_hit.alloc((size_t)n * 4));
+    double *d_o = b_o.as<double>(), *d_d = b_d.as<double>(), *d_len = b_len.as<double>(), *d_n = b_n.as<double>();
+    int32_t *d_hit = b_hit.as<int32_t>();
     HIP_TRY(hipMemcpy(d_o, org3, (size_t)n * 24, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir3, (size_t)n * 24, hipMemcpyHostToDevice));
     unsigned long long *d_keys = nullptr;
     if (keys) {
-        HIP_TRY(hipMalloc((void **)&d_keys, (size_t)n * 8));
+        HIP_TRY(b_keys.alloc((size_t)n * 8));
+        d_keys = b_keys.as<unsigned long long>();
         HIP_TRY(hipMemcpy(d_keys, keys, (size_t)n * 8, hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL(intersect_rays_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, obj, d_o, d_d, d_keys, n,
@@ -1731,8 +1742,6 @@ int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const 
     HIP_TRY(hipMemcpy(hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(normal3, d_n, (size_t)n * 24, hipMemcpyDeviceToHost));
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_len); (void)hipFree(d_n); (void)hipFree(d_hit);
-    if (d_keys) (void)hipFree(d_keys);
     return CGRT_OK;
 }
 

@@ -308,3 +308,26 @@ def test_bump_floor_grid_walk_vs_oracle(gpu_ready, orc, which):
     bumped = m & (np.abs(nw[:, 1]) < 1.0)
     print("%s: %d rays, %d hit the floor, %d of them on a tilted facet" % (which, len(o), m.sum(), bumped.sum()))
     assert bumped.sum() > 1000
+
+
+@pytest.mark.parametrize("mode", ["sah", "ref"])
+def test_both_hierarchies_are_exact(gpu_ready, orc, mode, monkeypatch):
+    """The device may walk either hierarchy over the reference's leaves -- its own SAH trees (per direction octant;
+    triangle-level for the opaque dragon-like mesh, leaf-level for the glass bunny) or, with CGRT_TREE=ref, the reference's
+    inner nodes; both must give the oracle's accumulator, hit counts and ray counts bit for bit."""
+    import cgraytracing_amd as cg
+    if mode == "ref":
+        monkeypatch.setenv("CGRT_TREE", "ref")
+    else:
+        monkeypatch.delenv("CGRT_TREE", raising=False)
+    opaque = scenes.TriangleMesh.from_triangles(scenes.procedural_mesh(48, 36, (6.0, -12.0, 28.0), 6.0), (0.25, 0.25, 0.5), 0.0, 0.0, 1)
+    mirror = scenes.TriangleMesh.from_triangles(scenes.procedural_mesh(24, 18, (-9.0, -13.0, 33.0), 4.0), (0.9, 0.9, 0.9), 0.8, 0.0, 1)
+    objs = scenes.scene_c3(True) + [opaque, mirror]
+    W, H, spp = 96, 80, 3
+    want = BackendScene(orc, objs).trace_grid(scenes.cam_dof(), W, H, spp, 5, seed=4242)
+    sc = cg.Scene(objs)
+    got = sc.trace_grid_host(W, H, spp, scenes.cam_dof(), 5, 4242)
+    sc.close()
+    assert got["nrays"] == want["nrays"]
+    assert np.array_equal(got["nhit"], want["nhit"])
+    assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
