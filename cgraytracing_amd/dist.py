@@ -90,3 +90,18 @@ class StripedRenderer:
     def frame(self):
         local = self.render_local(self.rows_local, self.stripe)
         return self.gather(local)
+
+
+def render_ppm_striped(scene, renderer, spp=1, camera=None, max_depth=5, seed=12345, **photon_args):
+    """The whole of render() (eye pass, photon pass, final gather) across the ranks of
+    `renderer` (a StripedRenderer): every rank traces all photons -- photon paths do not depend on hitpoints -- but
+    owns only the hitpoints of its stripes, so the expensive search / replay stages shard N ways and the assembled frame
+    equals a single-GPU render bit for bit.  Returns the [H, W, 3] float64 image on rank 0 (None elsewhere)."""
+    import torch
+
+    r = scene.ppm_render(renderer.W, renderer.H, spp, camera, max_depth, seed, rows=renderer.rows_local,
+                         stripe=renderer.stripe, **photon_args)
+    local = torch.from_numpy(r["image"])
+    if renderer.distributed and renderer.dist.get_backend(renderer.group) == "nccl":
+        local = local.to(torch.device("cuda", scene.device))
+    return renderer.gather(local)

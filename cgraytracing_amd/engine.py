@@ -184,13 +184,17 @@ class Scene:
 
     def ppm_render(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, nphotons=100000, photon_seed=777,
                    hashsize=1000001, light=(0.0, 19.999, 20.0), jitter=2.0, power=700.0, alpha=0.7, batch=0,
-                   want_hitpoints=False, want_rgb8=False):
+                   want_hitpoints=False, want_rgb8=False, rows=None, row_offset=0, stripe=None):
         """Eye pass + photon pass + final gather (+ tone map): render() main.cpp:169-258 with the serial photon
         semantics, and the PNG pixel loop of main.cpp:403-412.
-        Returns dict(image [H,W,3] float64 (row 0 = bottom), count, n_events, n_pairs, ms (stage times); with
-        want_hitpoints: hp [n,16]; with want_rgb8: rgb8 [H,W,3] uint8, top row first)."""
-        cc, g = self._structs(camera, width, height, height, spp, max_depth, seed, 0, None, 0, None, 0)
+        rows / row_offset / stripe select this rank's share of the frame exactly as in trace_grid (every rank traces
+        all photons and owns only its rows' hitpoints; the rows equal those of a full-frame call bit for bit).
+        Returns dict(image [rows,W,3] float64 (row 0 = bottom), count, n_events, n_pairs, ms (stage times); with
+        want_hitpoints: hp [n,16]; with want_rgb8 (contiguous rows only): rgb8 [rows,W,3] uint8, top row first)."""
+        rows = height if rows is None else rows
+        cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, 0, None, 0)
         ph = _capi.Photons(_d3(light), jitter, power, alpha, nphotons, hashsize, batch, photon_seed)
+        height = rows
         img = np.zeros((height, width, 3), np.float64)
         cap = height * width * spp * 16 if want_hitpoints else 0
         hp = np.zeros((max(cap, 1), 16), np.float64)

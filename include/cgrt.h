@@ -208,7 +208,12 @@ typedef struct cgrt_ppm_result {
 } cgrt_ppm_result;
 
 /* Eye pass + photon pass + final gather (+ tone map) for grid: the whole of render(), main.cpp:169-258, and the pixel
- * loop of main(), main.cpp:403-412.  Contiguous rows only (the hash table is global to the frame). */
+ * loop of main(), main.cpp:403-412.
+ * Sharding (multi-GPU): a hitpoint's history depends only on the ordered photon hits that reach it, never on other
+ * hitpoints, so a rank may own just the rows of its grid (a band, or block-cyclic stripes as in cgrt_trace_grid):
+ * it traces ALL photons but keeps, searches and updates only its own hitpoints, and its image rows are bit-identical
+ * to the same rows of a single full-frame call.  rgb8 needs contiguous rows (it flips them); hp16[0] is
+ * local_pixel*spp + sample. */
 int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, const cgrt_photons *ph,
                     cgrt_ppm_result *out);
 

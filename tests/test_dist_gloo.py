@@ -84,3 +84,51 @@ def test_stripe_mapping_is_a_partition():
 def test_assemble_single_rank_is_identity():
     x = torch.arange(2 * 3 * 4 * 3, dtype=torch.float32).reshape(1, 6, 4, 3)
     assert torch.equal(assemble(x, 5, 8, 1), x[0][:5])
+
+
+class _FakePpmScene:
+    """Stands in for cgraytracing_amd.Scene under gloo (no GPU): ppm_render returns a closed-form float64 'image' of
+    the global row, so render_ppm_striped's argument plumbing (rows, stripe) and the float64 gather are exercised."""
+    device = 0
+
+    def ppm_render(self, W, H, spp, camera, max_depth, seed, rows=None, stripe=None, **kw):
+        assert kw == {"nphotons": 1234}
+        s_rows, s_rank, s_n = stripe
+        gr = [global_row(j, s_rows, s_rank, s_n) for j in range(rows)]
+        img = _pattern(gr, W).double() * (1.0 + 1e-12)  # needs float64 to survive
+        img[torch.as_tensor(gr) >= H] = 0
+        return {"image": img.numpy()}
+
+
+def _ppm_worker(rank, world, port, W, H, S, q):
+    from cgraytracing_amd.dist import render_ppm_striped
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sr = StripedRenderer(W, H, stripe_rows=S)
+        frame = render_ppm_striped(_FakePpmScene(), sr, spp=2, nphotons=1234)
+        if rank == 0:
+            q.put(frame.numpy())
+        else:
+            assert frame is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_striped_ppm_gather_world2():
+    """Row f1 across ranks (cgraytracing_amd.dist.render_ppm_striped): float64 image rows gathered and un-permuted."""
+    W, H, S = 12, 40, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ppm_worker, args=(r, 2, port, W, H, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = (_pattern(list(range(H)), W).double() * (1.0 + 1e-12)).numpy()
+    assert frame.dtype == np.float64 and np.array_equal(frame, want)

@@ -168,3 +168,26 @@ def test_cpp_host_program_full_pipeline(gpu_ready, orc, tmp_path):
     g = np.load(os.path.join(GOLD, "ppm_c2_48x36.npz"))
     assert "hitpoints: %d" % len(g["hp"]) in out
     assert np.array_equal(np.asarray(Image.open(png).convert("RGB")), orc.tonemap(g["image"]))
+
+
+def test_ppm_render_shards_by_rows(gpu_ready):
+    """Row f1 x row e: a rank that owns only some rows (a band, or block-cyclic stripes) traces all photons but keeps
+    only its own hitpoints; its rows must equal the same rows of the full-frame render bit for bit, so the assembled
+    multi-GPU frame is the single-GPU frame.  Ranks are played one after another on the one GPU."""
+    import torch
+    import cgraytracing_amd as cg
+    from cgraytracing_amd import dist as cdist
+    objs = scenes.planes(scenes.stone_small_texture(True)) + [scenes.Sphere((5, -12, 30), 5, (1, 1, 1), 0.8, 0.5)]
+    W, H, spp, nph = 56, 40, 2, 30000
+    sc = cg.Scene(objs)
+    full = sc.ppm_render(W, H, spp, scenes.cam_dof(), 5, 12345, nphotons=nph)
+    band = sc.ppm_render(W, H, spp, scenes.cam_dof(), 5, 12345, nphotons=nph, rows=16, row_offset=8)
+    assert np.array_equal(band["image"], full["image"][8:24])
+    n, S = 3, 8
+    rows_local = cdist.local_rows(H, S, 0, n)
+    parts = [sc.ppm_render(W, H, spp, scenes.cam_dof(), 5, 12345, nphotons=nph, rows=rows_local, stripe=(S, r, n))["image"]
+             for r in range(n)]
+    sc.close()
+    frame = cdist.assemble(torch.from_numpy(np.stack(parts)), H, S, n).numpy()
+    assert np.array_equal(frame, full["image"])
+    assert full["image"].max() > 0.5
