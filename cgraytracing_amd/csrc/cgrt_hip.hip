@@ -977,7 +977,7 @@ struct HitpointSink {
 };
 
 template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false>
-__global__ __launch_bounds__(kThreads, BEZ ? 2 : ((GLASS && TREES) ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+__global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters,
                                                              HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {

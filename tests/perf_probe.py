@@ -12,26 +12,29 @@ import cgraytracing_amd as cg
 import scenes
 
 
-def run(name, objs, cam, W, H, spp, depth, reps=5, stats=False):
+def run(name, objs, cam, W, H, spp, depth, reps=5, stats=False, rows=None, row_offset=0):
     sc = cg.Scene(objs)
-    out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-    nh = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    rows = H if rows is None else rows
+    out = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+    nh = torch.zeros((rows, W), dtype=torch.int32, device="cuda")
     cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
-    sc.trace_grid(W, H, spp, cam, depth, 12345, out=out, nhit=nh, counters=cnt, stats=stats)
+    kw = dict(rows=rows, row_offset=row_offset)
+    sc.trace_grid(W, H, spp, cam, depth, 12345, out=out, nhit=nh, counters=cnt, stats=stats, **kw)
     torch.cuda.synchronize()
     cnt.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        sc.trace_grid(W, H, spp, cam, depth, 12345, out=out, nhit=nh, counters=cnt, stats=stats)
+        sc.trace_grid(W, H, spp, cam, depth, 12345, out=out, nhit=nh, counters=cnt, stats=stats, **kw)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     c = cnt.cpu().numpy() / reps
     rays = c[0]
     print("%-28s %4dx%-4d spp%-3d d%d  %8.3f ms  %9.1f Mrays/s  rays/px/s %.3f  util %.3f  nodes/ray %.1f tris/ray %.1f"
-          % (name, W, H, spp, depth, ms, rays / ms / 1e3, rays / (W * H * spp), rays / max(1, 64 * c[2]),
+          % (name, W, rows, spp, depth, ms, rays / ms / 1e3, rays / (W * rows * spp), rays / max(1, 64 * c[2]),
              c[3] / max(rays, 1), c[4] / max(rays, 1)), flush=True)
+    H = rows
     sc.close()
 
 
@@ -69,3 +72,6 @@ if __name__ == "__main__":
         run("c5 bump only", scenes.planes(tex), scenes.cam_dof(), 1024, 1024, 2, 5, reps=1, stats=True)
         run("c5 bump+vase", scenes.scene_c5(tex), scenes.cam_dof(), 1536, 1536, 2, 5, reps=1)
         run("vase only", scenes.planes() + [scenes.vase_bezier()], scenes.cam_dof(), 1536, 1536, 2, 5, reps=1)
+    if "c5band" in which:  # a slice of C5 at its real width: 256 rows through the vase, stone-sized bump floor
+        tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+        run("c5 band rows 3000..3255", scenes.scene_c5(tex), scenes.cam_dof(), 8192, 8192, 16, 5, reps=1, rows=256, row_offset=3000)
