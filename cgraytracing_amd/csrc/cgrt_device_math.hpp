@@ -1,0 +1,45 @@
+// Device-side Vec3 arithmetic in the reference's operation order (vec3.h:11-119).  Part of libcgrt.so (cgrt_hip.hip).
+#ifndef CGRT_DEVICE_MATH_HPP
+#define CGRT_DEVICE_MATH_HPP
+#include <hip/hip_runtime.h>
+
+#include "cgrt_rng.hpp"
+#include "cgrt_types.h"
+
+using namespace cgrt;
+
+// =====================================================================================================
+// device math: the reference's Vec3 (vec3.h:11-119), same operation order, no contraction
+// =====================================================================================================
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double f) { return mk(a.x * f, a.y * f, a.z * f); }
+__device__ __forceinline__ V3 mulv(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// vec3.h:36-44
+__device__ __forceinline__ V3 normalized(V3 a) {
+    double len = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (len > 0) {
+        double r = 1 / len;
+        a.x *= r;
+        a.y *= r;
+        a.z *= r;
+    }
+    return a;
+}
+// vec3.h:95-97, Sarrus with the reference's association
+__device__ __forceinline__ double det3(V3 a, V3 b, V3 c) {
+    return (a.x * b.y * c.z + b.x * c.y * a.z + c.x * a.y * b.z - a.x * c.y * b.z - b.x * a.y * c.z -
+            c.x * b.y * a.z);
+}
+__device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+
+#endif

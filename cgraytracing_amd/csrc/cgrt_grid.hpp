@@ -1,0 +1,79 @@
+// Kernel parameters of the eye pass, workgroup / tile constants, the block -> tile mapping.  Part of libcgrt.so (cgrt_hip.hip).
+#ifndef CGRT_GRID_HPP
+#define CGRT_GRID_HPP
+#include "cgrt_device_math.hpp"
+
+// =====================================================================================================
+// kernel parameters
+// =====================================================================================================
+struct GridParams {
+    int32_t W, H, rows, row_offset, stripe_rows, stripe_rank, stripe_nranks;
+    int32_t spp, sample_offset, max_depth;
+    int32_t accumulate;  // CGRT_GRID_ACCUMULATE: rgb += this pass (nhit is overwritten)
+    int32_t xcd_tiles;   // block -> tile mapping: 1 = XCD-aware super-tiles, 0 = row-major (see tile_of_block)
+    double inv_spp_total;
+    uint64_t seed;
+    double cam[3], half_width, focus_plane, lens_radius;
+};
+
+static constexpr int kTileW = 32, kTileH = 8, kThreads = 256;
+static constexpr int kMaxObjs = 96;  // top-level objects staged in LDS (12 KiB)
+// Pending refracted rays (main.cpp:157) of a lane, newest last:
+//   * a glass hit whose children are leaves of the recursion (depth_left == 2) keeps the refracted child in
+//     REGISTERS (it is consumed right after the reflected child, before any other push) -- in a full glass tree
+//     that is 8 of the 15 pushes;
+//   * the first two other levels live in LDS: per level 9 doubles + one packed (depth, path) word per thread,
+//     layout [level][field][thread] (conflict-free), 2 x 19 456 B = 38 912 B per workgroup;
+//   * a third level (three nested glass hits with all siblings waiting) spills to scratch memory.
+// The output tile aliases the stack (dead by then), so stack + objs stays under 40 KiB and FOUR workgroups fit a
+// CU's 160 KiB: occupancy 4 waves/SIMD instead of 3, worth ~10 % on C2.
+static constexpr int kPendDoubles = 9;
+static constexpr int kLdsLevels = 2;
+static constexpr size_t kLevelBytes = (size_t)kThreads * (kPendDoubles * sizeof(double) + sizeof(uint32_t));
+static constexpr size_t kStackBytes = (size_t)kLdsLevels * kLevelBytes;
+static constexpr size_t kTileBytes = (size_t)8 * 32 * 3 * sizeof(float);
+
+// local row -> global row (cgrt.h: block-cyclic stripes)
+__device__ __forceinline__ int global_row(const GridParams &g, int j) {
+    if (g.stripe_nranks > 1) {
+        int S = g.stripe_rows;
+        return ((j / S) * g.stripe_nranks + g.stripe_rank) * S + (j % S);
+    }
+    return g.row_offset + j;
+}
+
+// blockIdx -> tile, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2, so the
+// blocks b, b+8, b+16, ... share an L2.  Tiles are grouped in super-tiles of kSuperW x kSuperH tiles (128 x 32 pixels);
+// the blocks of one XCD group walk one super-tile after another, so the tiles an L2 serves at any moment are neighbours in
+// the image and want the same tree nodes, triangles and texels -- while successive super-tiles alternate between the XCD
+// groups, which keeps the expensive part of a frame (a mesh in one corner) spread over all of them.  Only placement
+// changes: every tile is still rendered exactly once by exactly one workgroup.
+// Measured (MI355X): C3 (glass bunny) 50.3 -> 46.6 ms, C4 (dragon) 205.5 -> 197.2 ms; but C2 4.05 -> 4.47 ms and the
+// Bezier vase 8.1 -> 9.0 ms -- scenes with no tree to share, whose expensive tiles (glass sphere, vase) then sit on
+// one or two XCDs.  So the launch picks it for scenes with meshes and no Bezier object, row-major otherwise.
+static constexpr int kXcds = 8, kSuperW = 4, kSuperH = 4, kSuperTiles = kSuperW * kSuperH;
+__host__ __device__ inline int tile_grid_blocks(int W, int rows, bool xcd_tiles) {
+    const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH;
+    if (!xcd_tiles) return tiles_x * tiles_y;
+    const int sx = (tiles_x + kSuperW - 1) / kSuperW, sy = (tiles_y + kSuperH - 1) / kSuperH;
+    const int nsuper = sx * sy;
+    return ((nsuper + kXcds - 1) / kXcds) * kXcds * kSuperTiles;
+}
+// false: this block has no tile (edge of the super-tile grid)
+__device__ __forceinline__ bool tile_of_block(const GridParams &g, int &tile_x, int &tile_y) {
+    const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
+    const int b = (int)blockIdx.x;
+    if (!g.xcd_tiles) {
+        tile_x = b % tiles_x;
+        tile_y = b / tiles_x;
+        return true;
+    }
+    const int sx = (tiles_x + kSuperW - 1) / kSuperW;
+    const int group = b % kXcds, q = b / kXcds;
+    const int super = (q / kSuperTiles) * kXcds + group, t = q % kSuperTiles;
+    tile_x = (super % sx) * kSuperW + t % kSuperW;
+    tile_y = (super / sx) * kSuperH + t / kSuperW;
+    return tile_x < tiles_x && tile_y < tiles_y;
+}
+
+#endif

@@ -1,0 +1,224 @@
+// Nearest hit over the top-level object list (main.cpp:55-63) and Texture::color.  Part of libcgrt.so (cgrt_hip.hip).
+#ifndef CGRT_SCENE_WALK_HPP
+#define CGRT_SCENE_WALK_HPP
+#include "cgrt_bezier.hpp"
+#include "cgrt_traverse.hpp"
+
+// =====================================================================================================
+// Texture::color, texture.h:39-72 (nearest texel, three axis-aligned orientations, d.x tested first)
+// =====================================================================================================
+__device__ __forceinline__ bool texture_color(const TexRec &t, const uint8_t *__restrict__ texels, V3 point, V3 &out) {
+    V3 d = point - ld3(t.p);
+    const V3 n = ld3(t.n);
+    d = d - n * dot(d, n);
+    const double te = 1e-2;  // texture.h:12
+    const int rows = t.rows, cols = t.cols;
+    int r, c;
+    if (d.x < te && d.x > -te) {
+        if (!(0 < d.y && d.y < t.lenx && 0 < d.z && d.z < t.leny)) return false;
+        r = (int)floor(d.y / t.lenx * rows);
+        c = (int)floor(d.z / t.leny * cols);
+    } else if (d.y < te && d.y > -te) {
+        if (!(0 < d.x && d.x < t.lenx && 0 < d.z && d.z < t.leny)) return false;
+        c = (int)floor(d.x / t.lenx * cols);
+        r = (int)floor(d.z / t.leny * rows);
+    } else if (d.z < te && d.z > -te) {
+        if (!(0 < d.x && d.x < t.lenx && 0 < d.y && d.y < t.leny)) return false;
+        c = (int)floor(d.x / t.lenx * cols);
+        r = rows - 1 - (int)floor(d.y / t.leny * rows);
+    } else {
+        return false;
+    }
+    // the reference indexes unchecked; an index equal to rows/cols can only arise from rounding at the far edge
+    r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+    c = c < 0 ? 0 : (c >= cols ? cols - 1 : c);
+    const uint8_t *px = texels + t.texel_begin + 3 * ((int64_t)r * cols + c);
+    out = mk((double)px[0] / 256.0, (double)px[1] / 256.0, (double)px[2] / 256.0);  // main.cpp:307-311
+    return true;
+}
+
+
+// =====================================================================================================
+// nearest hit over objs (main.cpp:55-63) -- all lanes walk the LDS-resident list in lockstep
+// =====================================================================================================
+struct SceneHit {
+    double t;
+    int id;  // -1: miss
+    V3 n;    // geometric normal as the object's intersect() returns it (before main.cpp:73-76)
+};
+
+// identifies a ray for the keyed Bezier stream: purpose_key(k_smp, (path << 16) | (object + 1)), or, for the
+// function-level probe, an explicit key
+struct RayKey {
+    uint64_t k;  // the sample's key k_smp (cgrt_rng.hpp), or the explicit stream key
+    uint32_t path;
+    bool explicit_key;
+    uint32_t n0;  // explicit key only: position in the stream; advanced by the draws consumed (photon pass)
+};
+
+// Sphere::intersect, objects.h:45-68: the hit distance, or +inf-like kInf (never < nearest) on a miss
+__device__ __forceinline__ double sphere_len(const ObjRec &ob, V3 o, V3 d) {
+    const V3 l = ld3(ob.a) - o;
+    const double tca = dot(l, d);
+    const double l2 = dot(l, l);
+    const double r2 = ob.s0;
+    double len = kInf;
+    if (!(tca < 0 && l2 > r2)) {
+        const double d2 = l2 - tca * tca;
+        if (!(d2 > r2)) {
+            const double thc = sqrt(r2 - d2);
+            const double t0 = tca - thc, t1 = tca + thc;
+            len = (t0 < 0) ? t1 : t0;
+        }
+    }
+    return len;
+}
+
+// One small tree (<= kNodeCache nodes: the bunny's 255, a coarse bump floor) is staged whole in LDS by every workgroup:
+// traversal is latency-bound on dependent node fetches, and an LDS read costs ~100 cycles against ~500-800 for L1/L2.
+static constexpr int kNodeCache = 256;  // 8 KiB of 32-byte nodes
+
+// per-workgroup LDS resources handed down to the scene walk
+struct LdsAux {
+    volatile BezLds *bl;    // this wave's Bezier scratch (BEZ variants) or nullptr
+    const NodeRec *lnodes;  // LDS copy of tree sc.cached_tree's nodes, or nullptr
+};
+
+// tree traversal entry; `on` = this lane really has a ray for this tree (all lanes of the wave call it).
+// A wave-synchronous variant (one shared node sequence, records fetched through the scalar cache) was measured
+// and dropped: with sub-pixel triangles the union of 64 rays' leaf sets approaches their sum.
+// `opaque` (wave-uniform): the owning object's transparency is < eps, so the pruned traversal applies with
+// `bound` = nearest hit distance already known for this ray.
+template <bool STATS>
+__device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux &aux, int tr, bool opaque, double bound,
+                                            bool on, V3 o, V3 d, V3 inv, uint32_t &n_node, uint32_t &n_tri) {
+    const TreeRec T = sc.trees[tr];
+    TreeHit none;
+    none.len = kInf;
+    none.tri = -1;
+    none.counter = 0;
+    if (!on) return none;
+    if (opaque && T.hfield >= 0) {  // bump floor: walk the grid instead of the tree (same triangles, same test)
+        const HFieldRec H = sc.hfields[T.hfield];
+        return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, o, d, inv, bound, n_node, n_tri);
+    }
+    const bool cached = aux.lnodes != nullptr && tr == sc.cached_tree;
+    // the copy of the hierarchy whose children are ordered near-to-far for this ray's direction octant (only worth a
+    // per-lane base address where order matters, i.e. for the pruned traversal)
+    const int oct = (T.noct == 8 && opaque) ? ((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) : 0;
+    const NodeRec *nodes = sc.nodes + T.node_begin + (size_t)oct * (size_t)T.nnodes;
+    const TriRec *tris = sc.tris + T.tri_begin;
+    if (opaque) {
+        if (T.tri_level) {
+            const OTriRec *ot = sc.otris + T.otri_begin;
+            if (cached) return tree_intersect<STATS, true, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, ot);
+            return tree_intersect<STATS, true, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, ot);
+        }
+        if (cached) return tree_intersect<STATS, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+        return tree_intersect<STATS, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+    }
+    if (cached) return tree_intersect<STATS, false>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+    return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+}
+
+template <bool TREES, bool BEZ, bool SPH, bool STATS>
+__device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
+                                                    V3 o, V3 d, RayKey &rk, bool on, const LdsAux &aux,
+                                                    uint32_t &n_node, uint32_t &n_tri) {
+    SceneHit best;
+    best.t = kInf;  // `nearest = INF`, main.cpp:54
+    best.id = -1;
+    best.n = mk(0, 0, 0);
+    int nsrc = 0;  // 0: sphere (normal derived after the loop), 1: stored in best.n
+    if (SPH) {
+        // scenes made of spheres only: no kind dispatch, nothing but (t, id) carried round the loop
+        for (int i = 0; i < n_objs; i++) {
+            const double len = sphere_len(objs[i], o, d);
+            if (len < best.t) {
+                best.t = len;
+                best.id = i;
+            }
+        }
+        if (best.id >= 0) best.n = normalized((o + d * best.t) - ld3(objs[best.id].a));  // objects.h:65-66
+        return best;
+    }
+    V3 inv = mk(0, 0, 0);
+    if (TREES) inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    for (int i = 0; i < n_objs; i++) {
+        const ObjRec &ob = objs[i];
+        const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
+        if (kind == KIND_SPHERE) {
+            const double len = sphere_len(ob, o, d);
+            if (len < best.t) {
+                best.t = len;
+                best.id = i;
+                nsrc = 0;
+            }
+        } else if (kind == KIND_PLANE) {
+            // Plane::intersect, objects.h:505-524
+            const V3 pn = ld3(ob.b);
+            const V3 dd = ld3(ob.a) - o;
+            double len = dot(dd, pn) / dot(d, pn);
+            const bool ph = len > 0;
+            V3 nrm = pn;
+            if (TREES) {
+                const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
+                const bool want = on && ph;  // the bump tree is only consulted when the plane is hit (objects.h:508-513)
+                if (tr >= 0 && __ballot(want) != 0ull) {
+                    // a bump hit only counts if it is nearer than the plane itself (objects.h:514) and, to matter,
+                    // nearer than the nearest object so far
+                    const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
+                    const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, fmin(len, best.t), want, o, d, inv, n_node, n_tri);
+                    if (want && h.counter > 0 && h.len < len && h.len > 0) {
+                        len = h.len;
+                        nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
+                    }
+                }
+            }
+            if (ph && len < best.t) {
+                best.t = len;
+                best.id = i;
+                best.n = nrm;
+                nsrc = 1;
+            }
+        } else if (TREES && kind == KIND_MESH) {
+            // TriangleMesh::intersect, objects.h:405-455
+            const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
+            if (__ballot(on) != 0ull) {
+                const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
+                const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, best.t, on, o, d, inv, n_node, n_tri);
+                if (on && h.counter > 0 && h.len < best.t) {
+                    V3 nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
+                    if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436
+                    best.t = h.len;
+                    best.id = i;
+                    best.n = nrm;
+                    nsrc = 1;
+                }
+            }
+        } else if (BEZ && kind == KIND_BEZIER) {
+            const BezierRec &bz = sc.beziers[__builtin_amdgcn_readfirstlane(ob.aux)];
+            const uint64_t key = rk.explicit_key ? rk.k : purpose_key(rk.k, ((uint64_t)rk.path << 16) | (uint64_t)(i + 1));
+            double len = 0;
+            V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
+            uint32_t n0 = rk.explicit_key ? rk.n0 : 0u;
+            const bool bh = bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, n0, len, nrm, aux.bl);
+            if (rk.explicit_key) rk.n0 = n0;
+            if (bh) {
+                if (len < best.t) {
+                    best.t = len;
+                    best.id = i;
+                    best.n = nrm;
+                    nsrc = 1;
+                }
+            }
+        }
+    }
+    if (best.id >= 0 && nsrc == 0) {
+        const V3 p = o + d * best.t;  // objects.h:65-66
+        best.n = normalized(p - ld3(objs[best.id].a));
+    }
+    return best;
+}
+
+#endif

@@ -1,0 +1,285 @@
+// Mesh traversal on the device: the stackless hierarchy walk with the reference's leaf scan, and the height-field walk
+// for opaque bump floors.  Part of libcgrt.so (cgrt_hip.hip).
+#ifndef CGRT_TRAVERSE_HPP
+#define CGRT_TRAVERSE_HPP
+#include "cgrt_device_math.hpp"
+#include "cgrt_grid.hpp"
+
+// =====================================================================================================
+// tree traversal: KDTree::intersect_subtree / KDTree::intersect (objects.h:269-332)
+// =====================================================================================================
+// The reference visits BOTH children of every inner node whose box the ray touches, scans every leaf it
+// reaches, and returns (a) the nearest triangle hit, ties resolved "first triangle inside a leaf, LAST leaf
+// across leaves" (strict < at objects.h:281 and 297) and (b) the total number of times a leaf's running minimum
+// improved, whose parity picks the normal's sign (objects.h:321-327).  Node numbering is preorder, so the
+// recursion is a linear scan with skip links; no stack is needed.
+//
+// Box test.  KDNode::intersect (objects.h:166-200) intersects the ray with each face plane of the box and
+// accepts when the crossing point lies within the face rectangle grown by 1e-4.  Whenever that accepts, the
+// ray touches the box grown by 1e-4 on all sides at some t > 0, so a slab test on the grown box accepts too.
+// Conversely a triangle of the node can only be hit at a point inside the un-grown box, where the reference's
+// exit-face test accepts with 1e-4 of margin.  So the slab test visits a superset of the reference's nodes
+// and the extra nodes cannot contain a hit: (len, triangle, counter) are identical.  The box is pre-grown by
+// kBoxPad on the host; 1/d is computed once per ray.
+//
+// Triangle test.  Triangle::intersect (objects.h:96-111) divides four determinants and compares the
+// quotients with 0 and 1.  For finite non-zero det1 the sign and "<= 1" tests on correctly rounded quotients
+// are equivalent to the sign / magnitude tests below (DESIGN.md "triangle test"), so only an accepted hit pays
+// for a division (len = det2/det1, the same correctly rounded quotient).
+struct TreeHit {
+    double len;
+    int tri;      // absolute index into tris[]
+    int counter;  // improvements (Q5)
+};
+
+//
+// PRUNE (opaque objects only).  The improvement counter only decides the SIGN of the returned normal, and trace()
+// re-orients the normal against the ray for every material (main.cpp:73-76); diffuse and mirror shading use
+// nothing else of it, so for an object whose transparency is < eps the counter cannot influence the image or
+// the Hitpoint records (the one exception is a ray exactly tangent to the winning triangle,
+// n.d == 0, where no re-orientation happens).  Then only the nearest hit matters, and a subtree whose box the
+// ray enters beyond `bound` -- the nearest hit known so far, in this tree or among the objects tested before
+// it -- can be skipped: a hit inside it would lose the strict `len < nearest` tests (objects.h:281,297;
+// main.cpp:57).  Entry distances come from the grown, outward-rounded boxes, so they never exceed the true
+// ones and a leaf holding a triangle that ties with the bound is still scanned: (len, triangle) stay exact.
+//
+// TRI (implies PRUNE): the hierarchy goes down to groups of <= 4 single triangles (`otris`, each carrying its place in
+// the reference's leaf order); with no leaf-wide scan order to rely on, every accepted hit is compared on
+// (len, reference leaf, index) directly -- the same winner as "first inside a leaf, last leaf across leaves".
+template <bool STATS, bool PRUNE, bool TRI = false>
+__device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                  int nnodes, V3 o, V3 d, V3 inv, double bound, uint32_t &n_node,
+                                                  uint32_t &n_tri, const OTriRec *__restrict__ otris = nullptr) {
+    TreeHit r;
+    r.len = kInf;
+    r.tri = -1;
+    r.counter = 0;
+    int r_leaf = -1;  // first triangle index of the leaf holding r.tri (grows with the reference's leaf sequence)
+    int i = 0;
+    // "while-while" traversal: every lane first walks inner nodes until it stands on a leaf its ray touches
+    // (or runs out of nodes); only then does the wave scan leaves, so the ~800-instruction leaf scan runs once
+    // per leaf-visit round with many lanes active instead of once per node step with one or two.
+    while (true) {
+        int leaf_begin = 0, leaf_cnt_tris = -1;
+        while (i < nnodes) {
+            // one 32-byte record = two 16-byte loads
+            const float4 q0 = reinterpret_cast<const float4 *>(nodes + i)[0];  // lo.x lo.y lo.z hi.x
+            const float4 q1 = reinterpret_cast<const float4 *>(nodes + i)[1];  // hi.y hi.z skip leaf
+            if (STATS) n_node++;
+            double t1, t2, tn, tf;
+            t1 = ((double)q0.x - o.x) * inv.x;
+            t2 = ((double)q0.w - o.x) * inv.x;
+            tn = fmin(t1, t2);
+            tf = fmax(t1, t2);
+            t1 = ((double)q0.y - o.y) * inv.y;
+            t2 = ((double)q1.x - o.y) * inv.y;
+            tn = fmax(tn, fmin(t1, t2));
+            tf = fmin(tf, fmax(t1, t2));
+            t1 = ((double)q0.z - o.z) * inv.z;
+            t2 = ((double)q1.y - o.z) * inv.z;
+            tn = fmax(tn, fmin(t1, t2));
+            tf = fmin(tf, fmax(t1, t2));
+            const bool touch = (tf > 0.0) && (tn <= tf) && !(PRUNE && tn > bound);
+            const int leaf = __float_as_int(q1.w);
+            if (!touch) {
+                i = __float_as_int(q1.z);
+                continue;
+            }
+            i = i + 1;  // inner: left child is next in preorder; leaf: its skip is i+1 too
+            if (leaf < 0) continue;
+            leaf_begin = leaf >> 4;
+            leaf_cnt_tris = leaf & 15;
+            break;
+        }
+        if (leaf_cnt_tris < 0) break;  // no further leaf for this lane
+        if (TRI) {
+            const OTriRec *tp = otris + leaf_begin;
+            for (int k = 0; k < leaf_cnt_tris; k++) {
+                if (STATS) n_tri++;
+                const V3 pa = ld3(tp[k].t.pa), e1 = ld3(tp[k].t.e1), e2 = ld3(tp[k].t.e2);
+                const int2 rank = *reinterpret_cast<const int2 *>(&tp[k].k);  // k, leaf
+                const V3 s = pa - o;
+                const double det1 = det3(d, e1, e2);
+                const double det2 = det3(s, e1, e2);
+                const double det3_ = det3(d, s, e2);
+                const double det4 = det3(d, e1, s);
+                const double sg = det1 > 0.0 ? 1.0 : -1.0;
+                const double a1 = det1 * sg;
+                const bool ok = (det1 != 0.0) && (det2 * sg > 0.0) && (det3_ * sg >= 0.0) && (det4 * sg >= 0.0) &&
+                                ((det3_ + det4) * sg <= a1);
+                if (ok) {
+                    const double len = det2 / det1;
+                    if (len < r.len || (len == r.len && (rank.y > r_leaf || (rank.y == r_leaf && rank.x < r.tri)))) {
+                        r.len = len;
+                        r.tri = rank.x;
+                        r_leaf = rank.y;
+                        r.counter = 1;
+                    }
+                }
+            }
+            if (r.len < bound) bound = r.len;
+            continue;
+        }
+        // leaf scan, objects.h:273-289
+        double leaf_len = kInf;
+        int leaf_tri = -1, leaf_cnt = 0;
+        const TriRec *tp = tris + leaf_begin;
+        // one triangle ahead: the next record is requested before the current one is tested (every request is used
+        // except the repeat of the last one, so this adds no traffic)
+        V3 pa = ld3(tp[0].pa), e1 = ld3(tp[0].e1), e2 = ld3(tp[0].e2);
+        for (int k = 0; k < leaf_cnt_tris; k++) {
+            if (STATS) n_tri++;
+            const int kn = (k + 1 < leaf_cnt_tris) ? k + 1 : k;
+            const V3 npa = ld3(tp[kn].pa), ne1 = ld3(tp[kn].e1), ne2 = ld3(tp[kn].e2);
+            const V3 s = pa - o;
+            const double det1 = det3(d, e1, e2);
+            const double det2 = det3(s, e1, e2);
+            const double det3_ = det3(d, s, e2);
+            const double det4 = det3(d, e1, s);
+            const double sg = det1 > 0.0 ? 1.0 : -1.0;
+            const double a1 = det1 * sg;
+            const bool ok = (det1 != 0.0) && (det2 * sg > 0.0) && (det3_ * sg >= 0.0) && (det4 * sg >= 0.0) &&
+                            ((det3_ + det4) * sg <= a1);
+            if (ok) {
+                const double len = det2 / det1;
+                if (len < leaf_len) {
+                    leaf_len = len;
+                    leaf_tri = leaf_begin + k;
+                    leaf_cnt++;
+                }
+            }
+            pa = npa;
+            e1 = ne1;
+            e2 = ne2;
+        }
+        if (leaf_cnt > 0) {
+            // objects.h:295-313: the left result survives only if strictly nearer => the LATER leaf of the reference's
+            // sequence wins ties.  Spelled out on the leaf's position, because the hierarchy above the leaves need not
+            // visit them in the reference's order.
+            if (r.counter == 0 || leaf_len < r.len || (leaf_len == r.len && leaf_begin > r_leaf)) {
+                r.len = leaf_len;
+                r.tri = leaf_tri;
+                r_leaf = leaf_begin;
+            }
+            r.counter += leaf_cnt;
+            if (PRUNE && r.len < bound) bound = r.len;
+        }
+    }
+    return r;
+}
+
+// =====================================================================================================
+// Opaque bump floors: the displacement mesh as a height field
+// =====================================================================================================
+// The reference pushes every floor-bound ray through its object-median tree over the bump mesh -- for the stone
+// floor 192 node tests and 179 triangle tests per ray on average, because both children are always visited and
+// preorder is not front to back.  The mesh is a regular grid of quads in x-z (objects.h:485-497), so for an OPAQUE
+// floor (where only the nearest hit matters, see PRUNE above) the ray is clipped to the slab of heights the mesh
+// occupies and walked column by column along its major horizontal axis; the two triangles of every cell the ray's
+// footprint touches are tested with the SAME triangle records and the SAME test as the tree's leaves, so an accepted
+// hit has the same `len`, bit for bit.  A hit point lies inside its triangle, hence over its cell, so the walk --
+// padded by kHfPad on every side against rounding -- meets every triangle the ray can hit; columns are visited in
+// ray order and the walk stops at the first column that begins beyond the nearest hit.  Exact ties (a ray through
+// a shared edge) are resolved as the tree resolves them: the triangle in the LATER leaf wins, inside a leaf the
+// EARLIER one (objects.h:281,297) -- each cell record carries its triangles' leaf number and leaf-order index.
+static constexpr double kHfPad = 1e-9;
+
+template <bool STATS>
+__device__ __forceinline__ TreeHit hfield_intersect(const HFieldRec &H, const HCellRec *__restrict__ cells, V3 o, V3 d,
+                                                    V3 inv, double bound, uint32_t &n_node, uint32_t &n_tri) {
+    TreeHit r;
+    r.len = kInf;
+    r.tri = -1;
+    r.counter = 0;
+    int best_leaf = -1;
+    // clip the ray's parameter range (0, bound] to the padded box of the mesh
+    double ta = 0.0, tb = bound;
+    const double lo[3] = {H.x0 - kHfPad, H.ylo - kHfPad, H.z0 - kHfPad};
+    const double hi[3] = {H.x0 + H.hx * H.nx + kHfPad, H.yhi + kHfPad, H.z0 + H.hz * H.nz + kHfPad};
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv.x, inv.y, inv.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (dd[k] != 0.0) {
+            const double t1 = (lo[k] - oo[k]) * ii[k], t2 = (hi[k] - oo[k]) * ii[k];
+            ta = fmax(ta, fmin(t1, t2));
+            tb = fmin(tb, fmax(t1, t2));
+        } else if (oo[k] < lo[k] || oo[k] > hi[k]) {
+            tb = -1.0;
+        }
+    }
+    if (!(ta <= tb)) return r;
+    // major axis: the one along which the ray crosses more cells
+    const bool xmaj = fabs(d.x) * H.hz >= fabs(d.z) * H.hx;
+    const double oM = xmaj ? o.x : o.z, dM = xmaj ? d.x : d.z, iM = xmaj ? inv.x : inv.z;
+    const double om = xmaj ? o.z : o.x, dm = xmaj ? d.z : d.x;
+    const double M0 = xmaj ? H.x0 : H.z0, hM = xmaj ? H.hx : H.hz, m0 = xmaj ? H.z0 : H.x0, hm = xmaj ? H.hz : H.hx;
+    const int nM = xmaj ? H.nx : H.nz, nm = xmaj ? H.nz : H.nx;
+    const double ihM = 1.0 / hM, ihm = 1.0 / hm;
+    const double Ma = oM + dM * ta, Mb = oM + dM * tb;
+    int j0 = (int)floor((fmin(Ma, Mb) - kHfPad - M0) * ihM), j1 = (int)floor((fmax(Ma, Mb) + kHfPad - M0) * ihM);
+    j0 = j0 < 0 ? 0 : j0;
+    j1 = j1 > nM - 1 ? nM - 1 : j1;
+    const int step = dM >= 0.0 ? 1 : -1;
+    const int jn = j1 - j0 + 1;  // columns to visit (<= 0: none)
+    int j = step > 0 ? j0 : j1;
+    for (int c = 0; c < jn; c++, j += step) {
+        // parameter range of the padded column, within [ta, tb]
+        double s0 = ta, s1 = tb;
+        if (dM != 0.0) {
+            const double t1 = (M0 + hM * j - kHfPad - oM) * iM, t2 = (M0 + hM * (j + 1) + kHfPad - oM) * iM;
+            s0 = fmax(s0, fmin(t1, t2));
+            s1 = fmin(s1, fmax(t1, t2));
+        }
+        if (s0 > r.len) break;   // this column and all later ones begin beyond the nearest hit
+        if (!(s0 <= s1)) continue;
+        const double ma = om + dm * s0, mb = om + dm * s1;
+        int i0 = (int)floor((fmin(ma, mb) - kHfPad - m0) * ihm), i1 = (int)floor((fmax(ma, mb) + kHfPad - m0) * ihm);
+        i0 = i0 < 0 ? 0 : i0;
+        i1 = i1 > nm - 1 ? nm - 1 : i1;
+        for (int i = i0; i <= i1; i++) {
+            if (STATS) n_node++;
+            const HCellRec *cell = cells + (xmaj ? (size_t)i * H.nx + j : (size_t)j * H.nx + i);
+            const int4 ids = *reinterpret_cast<const int4 *>(cell->k);  // k0 k1 leaf0 leaf1
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (STATS) n_tri++;
+                const V3 pa = ld3(cell->t[q].pa), e1 = ld3(cell->t[q].e1), e2 = ld3(cell->t[q].e2);
+                const V3 s = pa - o;
+                const double det1 = det3(d, e1, e2);
+                const double det2 = det3(s, e1, e2);
+                const double det3_ = det3(d, s, e2);
+                const double det4 = det3(d, e1, s);
+                const double sg = det1 > 0.0 ? 1.0 : -1.0;
+                const double a1 = det1 * sg;
+                const bool ok = (det1 != 0.0) && (det2 * sg > 0.0) && (det3_ * sg >= 0.0) && (det4 * sg >= 0.0) &&
+                                ((det3_ + det4) * sg <= a1);
+                if (ok) {
+                    const double len = det2 / det1;
+                    const int k = q ? ids.y : ids.x, leaf = q ? ids.w : ids.z;
+                    if (len < r.len || (len == r.len && (leaf > best_leaf || (leaf == best_leaf && k < r.tri)))) {
+                        r.len = len;
+                        r.tri = k;
+                        best_leaf = leaf;
+                        r.counter = 1;
+                    }
+                }
+            }
+        }
+    }
+    return r;
+}
+
+// normal of the winning triangle, oriented by the improvement-counter parity (objects.h:107,321-327)
+__device__ __forceinline__ V3 tree_normal(const TriRec *__restrict__ tris, const TreeHit &h, V3 d) {
+    const V3 e1 = ld3(tris[h.tri].e1), e2 = ld3(tris[h.tri].e2);
+    V3 n = normalized(cross(e1, e2));
+    const bool facing = dot(n, d) < 0;
+    if ((h.counter & 1) == 0) {
+        if (!facing) n = -n;  // origin outside: normal against the ray
+    } else {
+        if (facing) n = -n;  // origin inside: normal along the ray
+    }
+    return n;
+}
+
+#endif
