@@ -2,6 +2,10 @@
 #include "cgrt_build.h"
 
 #include <algorithm>
+#include <atomic>
+#include <future>
+#include <thread>
+#include <unordered_map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,8 +48,21 @@ struct Builder {
         const double *t = &T[9 * (size_t)id];
         return hi3(t[axis], t[3 + axis], t[6 + axis]);
     }
-    void emit(size_t b, size_t e, int axis) {
-        const int32_t me = (int32_t)out.nodes.size();
+    // Node numbers and leaf positions follow from the triangle counts alone (a node of n >= 10 triangles has children of
+    // n/2 and n - n/2; the leaves partition the id array in order), so every node knows its number before its subtree
+    // exists: `me` for itself, me + 1 for the left child, me + 1 + nodes(n/2) for the right one, and a leaf over ids[b, e)
+    // owns tris[b, e).  That makes the two halves of a node independent pieces of work -- the sorts touch disjoint slices
+    // -- and the top of the tree is built by several threads; the output is the serial build's, element for element.
+    std::unordered_map<size_t, size_t> node_count;
+    size_t count_nodes(size_t n) {  // fills the memo (call once from one thread before emit)
+        auto it = node_count.find(n);
+        if (it != node_count.end()) return it->second;
+        const size_t c = ((int)n < kMinKd) ? 1 : 1 + count_nodes(n / 2) + count_nodes(n - n / 2);
+        node_count[n] = c;
+        return c;
+    }
+    size_t nodes_of(size_t n) const { return node_count.at(n); }
+    void emit(size_t b, size_t e, int axis, int32_t me, int depth) {
         const size_t n = e - b;
         double mx[3] = {-kInf, -kInf, -kInf}, mn[3] = {kInf, kInf, kInf};  // objects.h:227-232
         for (size_t i = b; i < e; i++) {
@@ -61,18 +78,18 @@ struct Builder {
             nr.lo[k] = round_down(mn[k] - kBoxPad);
             nr.hi[k] = round_up(mx[k] + kBoxPad);
         }
-        nr.skip = 0;
+        nr.skip = me + (int32_t)nodes_of(n);
         nr.leaf = -1;
-        out.nodes.push_back(nr);
-        out.node_lr_size.push_back(-1);
-        out.node_lr_size.push_back(-1);
-        out.node_lr_size.push_back((int32_t)n);
+        out.node_lr_size[3 * (size_t)me + 0] = -1;
+        out.node_lr_size[3 * (size_t)me + 1] = -1;
+        out.node_lr_size[3 * (size_t)me + 2] = (int32_t)n;
         for (int k = 0; k < 3; k++) {
-            out.bbox.push_back(mn[k]);
-            out.bbox.push_back(mx[k]);
+            out.bbox[6 * (size_t)me + 2 * (size_t)k] = mn[k];
+            out.bbox[6 * (size_t)me + 2 * (size_t)k + 1] = mx[k];
         }
         if ((int)n < kMinKd) {  // leaf (objects.h:251, 273)
-            out.nodes[me].leaf = (int32_t)(((uint32_t)out.tris.size() << 4) | (uint32_t)n);
+            nr.leaf = (int32_t)(((uint32_t)b << 4) | (uint32_t)n);
+            out.nodes[(size_t)me] = nr;
             for (size_t i = b; i < e; i++) {
                 const double *t = &T[9 * (size_t)ids[i]];
                 TriRec tr;
@@ -81,21 +98,27 @@ struct Builder {
                     tr.e1[k] = t[k] - t[3 + k];  // pa - pb (objects.h:98)
                     tr.e2[k] = t[k] - t[6 + k];  // pa - pc (objects.h:99)
                 }
-                out.tris.push_back(tr);
-                out.leaf_ids.push_back(ids[i]);
+                out.tris[i] = tr;
+                out.leaf_ids[i] = ids[i];
             }
-            out.nodes[me].skip = me + 1;
             return;
         }
+        out.nodes[(size_t)me] = nr;
         std::sort(ids.begin() + b, ids.begin() + e,
                   [this, axis](int32_t p, int32_t q) { return key(p, axis) < key(q, axis); });
         const size_t mid = b + n / 2;
         const int next_axis = (axis + 1) % 3;
-        out.node_lr_size[3 * (size_t)me + 0] = (int32_t)out.nodes.size();
-        emit(b, mid, next_axis);
-        out.node_lr_size[3 * (size_t)me + 1] = (int32_t)out.nodes.size();
-        emit(mid, e, next_axis);
-        out.nodes[me].skip = (int32_t)out.nodes.size();
+        const int32_t left = me + 1, right = me + 1 + (int32_t)nodes_of(n / 2);
+        out.node_lr_size[3 * (size_t)me + 0] = left;
+        out.node_lr_size[3 * (size_t)me + 1] = right;
+        if (depth < 3 && n > 16384) {
+            std::future<void> fl = std::async(std::launch::async, [=] { emit(b, mid, next_axis, left, depth + 1); });
+            emit(mid, e, next_axis, right, depth + 1);
+            fl.get();
+        } else {
+            emit(b, mid, next_axis, left, depth + 1);
+            emit(mid, e, next_axis, right, depth + 1);
+        }
     }
 };
 
@@ -181,11 +204,17 @@ void HostTree::build(bool opaque, bool with_bvh) {
     node_lr_size.clear();
     bbox.clear();
     leaf_ids.clear();
-    Builder b{tri9, {}, *this};
+    Builder b{tri9, {}, *this, {}};
     const size_t n = tri9.size() / 9;
     b.ids.resize(n);
     for (size_t i = 0; i < n; i++) b.ids[i] = (int32_t)i;
-    b.emit(0, n, 0);
+    const size_t nn = b.count_nodes(n);
+    nodes.resize(nn);
+    node_lr_size.resize(3 * nn);
+    bbox.resize(6 * nn);
+    tris.resize(n);
+    leaf_ids.resize(n);
+    b.emit(0, n, 0, 0, 0);
     if (with_bvh) build_bvh(opaque);
 }
 
@@ -212,7 +241,8 @@ struct BvhTmp {
 struct BvhBuilder {
     std::vector<BvhItem> items;
     std::vector<int32_t> idx;
-    std::vector<BvhTmp> nodes;
+    std::vector<BvhTmp> nodes;          // preallocated (2 * items); slots are claimed through `next`, so node NUMBERS depend on
+    std::atomic<int32_t> next{0};       // thread timing -- the tree's shape, and everything emitted from it, does not
     size_t max_leaf = 1;  // 1: one item (a reference leaf) per leaf, leafref = the item's; > 1: items are triangles and
                           // a leaf is a run of idx, leafref = (first position << 4) | count
 
@@ -234,8 +264,8 @@ struct BvhBuilder {
                 chi[k] = std::max(chi[k], c);
             }
         }
-        const int32_t me = (int32_t)nodes.size();
-        nodes.push_back(nd);
+        const int32_t me = next.fetch_add(1);
+        nodes[(size_t)me] = nd;
         if (e - b <= max_leaf) {
             nodes[(size_t)me].leafref = max_leaf == 1 ? items[(size_t)idx[b]].leafref : (int32_t)((b << 4) | (e - b));
             return me;
@@ -308,8 +338,15 @@ struct BvhBuilder {
             });
         }
         if (mid == b || mid == e) mid = b + (e - b) / 2;
-        const int32_t l = build(b, mid, depth + 1);
-        const int32_t r = build(mid, e, depth + 1);
+        int32_t l, r;
+        if (depth < 3 && e - b > 16384) {  // the two halves touch disjoint slices of idx: build them side by side
+            std::future<int32_t> fl = std::async(std::launch::async, [this, b, mid, depth] { return build(b, mid, depth + 1); });
+            r = build(mid, e, depth + 1);
+            l = fl.get();
+        } else {
+            l = build(b, mid, depth + 1);
+            r = build(mid, e, depth + 1);
+        }
         BvhTmp &m = nodes[(size_t)me];
         m.left = l;
         m.right = r;
@@ -318,9 +355,10 @@ struct BvhBuilder {
         m.left_is_lower = (L.lo[axis] + L.hi[axis]) <= (R.lo[axis] + R.hi[axis]);
         return me;
     }
-    void emit(int32_t n, int oct, std::vector<NodeRec> &out) const {
+    // preorder with skip links into out[0..): `cur` is the next free slot of this octant's array
+    void emit(int32_t n, int oct, NodeRec *out, int32_t &cur) const {
         const BvhTmp &t = nodes[(size_t)n];
-        const size_t me = out.size();
+        const int32_t me = cur++;
         NodeRec nr;
         for (int k = 0; k < 3; k++) {
             nr.lo[k] = round_down(t.lo[k] - kBoxPad);
@@ -328,16 +366,15 @@ struct BvhBuilder {
         }
         nr.skip = 0;
         nr.leaf = t.leafref;
-        out.push_back(nr);
+        out[me] = nr;
         if (t.leafref < 0) {
             const bool positive = ((oct >> t.axis) & 1) == 0;  // octant bit set = direction component negative
             const bool left_first = (positive == t.left_is_lower);
-            emit(left_first ? t.left : t.right, oct, out);
-            emit(left_first ? t.right : t.left, oct, out);
+            emit(left_first ? t.left : t.right, oct, out, cur);
+            emit(left_first ? t.right : t.left, oct, out, cur);
         }
-        out[me].skip = (int32_t)(out.size() - base);
+        out[me].skip = cur;
     }
-    size_t base = 0;
 };
 }  // namespace
 
@@ -381,13 +418,18 @@ void HostTree::build_bvh(bool opaque) {
     if (B.items.empty()) return;
     B.idx.resize(B.items.size());
     for (size_t i = 0; i < B.idx.size(); i++) B.idx[i] = (int32_t)i;
-    B.nodes.reserve(2 * B.items.size());
-    B.build(0, B.items.size(), 0);
-    bvh_nodes = (int32_t)B.nodes.size();
-    bvh.reserve((size_t)bvh_nodes * 8);
-    for (int oct = 0; oct < 8; oct++) {
-        B.base = bvh.size();
-        B.emit(0, oct, bvh);
+    B.nodes.resize(2 * B.items.size());
+    const int32_t root = B.build(0, B.items.size(), 0);
+    bvh_nodes = B.next.load();
+    bvh.resize((size_t)bvh_nodes * 8);
+    {  // the eight layouts are independent: one thread each
+        std::vector<std::thread> th;
+        for (int oct = 0; oct < 8; oct++)
+            th.emplace_back([&, oct] {
+                int32_t cur = 0;
+                B.emit(root, oct, bvh.data() + (size_t)oct * (size_t)bvh_nodes, cur);
+            });
+        for (auto &t : th) t.join();
     }
     if (opaque) {  // triangle records in the hierarchy's own order, each with its rank for ties
         otris.resize(tris.size());
