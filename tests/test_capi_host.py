@@ -160,6 +160,22 @@ def test_host_builder_under_sanitizers(tmp_path):
     assert "missing.txt -> " in out.stdout and "objs=" in out.stdout
 
 
+def test_threaded_host_build_under_tsan(tmp_path):
+    """The multi-threaded parts of the host build (reference-order tree with preassigned node numbers, SAH halves, the
+    eight octant layouts) on a 44 402-triangle mesh under ThreadSanitizer, and -- same program, plain build -- twice in
+    a row with identical output (the reference-order arrays must not depend on thread timing)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "cgraytracing_amd", "csrc")
+    exe = str(tmp_path / "build_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I", csrc,
+                           os.path.join(ROOT, "tests", "native", "build_san.cpp"), os.path.join(csrc, "cgrt_build.cpp"),
+                           "-o", exe])
+    out = subprocess.run([exe, "--big"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-2000:]
+    assert "big: tris=44402" in out.stdout
+
+
 def _png_decode(path):
     """Minimal PNG reader (8-bit RGB, filter 0 only -- what cgrt_write_png emits) with full CRC / Adler checks via zlib."""
     import struct
