@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -125,19 +126,31 @@ int cgrt_scene_add_plane(cgrt_scene *s, const double p[3], const double n[3], co
                          double transp, int tex_id) {
     NEED_OPEN(s);
     if (!p || !n || !sc) return fail(CGRT_ERR_INVALID, "null argument");
-    return added(s, s->host.add_plane(p, n, sc, refl, transp, tex_id));
+    try {  // the tree build allocates and starts threads: nothing may unwind through the C ABI
+        return added(s, s->host.add_plane(p, n, sc, refl, transp, tex_id));
+    } catch (const std::exception &e) {
+        return fail(CGRT_ERR_LIMIT, std::string("plane: ") + e.what());
+    }
 }
 int cgrt_scene_add_mesh_file(cgrt_scene *s, const char *filename, double a, const double b[3], const double sc[3],
                              double refl, double transp, int typeofdata) {
     NEED_OPEN(s);
     if (!filename || !b || !sc) return fail(CGRT_ERR_INVALID, "null argument");
-    return added(s, s->host.add_mesh_file(filename, a, b, sc, refl, transp, typeofdata));
+    try {
+        return added(s, s->host.add_mesh_file(filename, a, b, sc, refl, transp, typeofdata));
+    } catch (const std::exception &e) {
+        return fail(CGRT_ERR_LIMIT, std::string("mesh: ") + e.what());
+    }
 }
 int cgrt_scene_add_mesh_triangles(cgrt_scene *s, const double *tri9, int ntri, const double sc[3], double refl,
                                   double transp, int typeofdata) {
     NEED_OPEN(s);
     if (!sc) return fail(CGRT_ERR_INVALID, "null argument");
-    return added(s, s->host.add_mesh_triangles(tri9, ntri, sc, refl, transp, typeofdata));
+    try {
+        return added(s, s->host.add_mesh_triangles(tri9, ntri, sc, refl, transp, typeofdata));
+    } catch (const std::exception &e) {
+        return fail(CGRT_ERR_LIMIT, std::string("mesh: ") + e.what());
+    }
 }
 int cgrt_scene_add_bezier(cgrt_scene *s, const double *cp3, int ncp, const double pos[3], const double sc[3],
                           double refl, double transp) {
