@@ -445,7 +445,9 @@ void HostTree::build_bvh(bool opaque) {
 // Grid-ordered view of a bump floor's triangles (call after build()).
 void HostTree::build_hfield(int nx, int nz, double x0, double z0, double hx, double hz) {
     const size_t ntri = tri9.size() / 9;
+    // a grid walk needs a proper grid: positive, finite pitch (a texture with lenx <= 0 keeps the tree)
     if (nx < 1 || nz < 1 || ntri != (size_t)nx * nz * 2 || tris.size() != ntri) return;
+    if (!(hx > 0) || !(hz > 0) || !std::isfinite(hx) || !std::isfinite(hz) || !std::isfinite(x0) || !std::isfinite(z0)) return;
     std::vector<int32_t> pos(ntri), leaf_of(ntri);
     for (size_t k = 0; k < ntri; k++) pos[(size_t)leaf_ids[k]] = (int32_t)k;
     for (const NodeRec &nd : nodes)
