@@ -38,6 +38,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Camera) == 48
     assert C.sizeof(_capi.Grid) == 56  # 12 x int32 + uint64
     assert C.sizeof(_capi.SceneStats) == 8 * 4 + 4 * 8
+    assert C.sizeof(_capi.Photons) == 72       # 6 doubles, int64, 2 x int32, uint64 (pinned in tests/native/abi_c99.c too)
+    assert C.sizeof(_capi.PpmResult) == 88     # 3 pointers, 4 x uint64, 4 doubles
 
 
 def test_error_reporting_without_gpu_or_bad_args():
