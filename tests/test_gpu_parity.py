@@ -331,3 +331,46 @@ def test_both_hierarchies_are_exact(gpu_ready, orc, mode, monkeypatch):
     assert got["nrays"] == want["nrays"]
     assert np.array_equal(got["nhit"], want["nhit"])
     assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
+
+
+def _random_mesh(rng, ntri, center, size, dup_frac):
+    """Random triangle soup around `center`: some triangles share vertices / edges, a fraction are exact duplicates of
+    others (equal distances from different leaves: the tie rules), a few are degenerate (zero area)."""
+    verts = center + (rng.random((max(4, ntri), 3)) - 0.5) * size
+    tris = []
+    for _ in range(ntri):
+        if tris and rng.random() < dup_frac:
+            tris.append(tris[rng.integers(len(tris))].copy())
+        else:
+            idx = rng.integers(0, len(verts), 3)
+            if rng.random() < 0.03:
+                idx[2] = idx[1]  # degenerate
+            tris.append(verts[idx].reshape(9))
+    return np.asarray(tris, np.float64)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_match_oracle_exactly(gpu_ready, orc, seed):
+    """Fuzz: random triangle soups (duplicates, shared edges, degenerate triangles; 1 to ~400 triangles, so trees from a
+    single leaf to several levels) as opaque, mirror and glass objects, plus random spheres, inside the reference's box of
+    planes; pinhole or thin lens.  Accumulator, per-pixel hit counts and ray count must equal the oracle's exactly."""
+    import cgraytracing_amd as cg
+    rng = np.random.default_rng(1000 + seed)
+    objs = [scenes.Sphere(tuple(rng.uniform((-12, -15, 20), (12, 5, 36))), float(rng.uniform(1.5, 4.0)),
+                          tuple(rng.uniform(0.2, 1.0, 3)), *[(0.0, 0.0), (0.8, 0.0), (0.8, 0.5)][rng.integers(3)])
+            for _ in range(int(rng.integers(0, 3)))]
+    objs += scenes.planes(scenes.chessboard_texture(bool(seed % 2)) if seed % 3 == 0 else None)
+    for k in range(int(rng.integers(1, 4))):
+        ntri = int([1, 9, 10, 11, 40, 150, 400][rng.integers(7)])
+        refl, transp = [(0.0, 0.0), (0.8, 0.0), (0.8, 0.5)][(seed + k) % 3]
+        tri = _random_mesh(rng, ntri, rng.uniform((-10, -16, 22), (10, 0, 34)), float(rng.uniform(3.0, 9.0)), 0.15)
+        objs.append(scenes.TriangleMesh.from_triangles(tri, tuple(rng.uniform(0.2, 1.0, 3)), refl, transp, int(rng.integers(0, 3))))
+    cam = scenes.cam_dof() if seed % 2 else scenes.cam_pinhole()
+    W, H, spp = 64, 48, 2
+    want = BackendScene(orc, objs).trace_grid(cam, W, H, spp, 5, seed=77 + seed)
+    sc = cg.Scene(objs)
+    got = sc.trace_grid_host(W, H, spp, cam, 5, 77 + seed)
+    sc.close()
+    assert got["nrays"] == want["nrays"]
+    assert np.array_equal(got["nhit"], want["nhit"])
+    assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
