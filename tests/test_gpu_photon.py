@@ -191,3 +191,27 @@ def test_ppm_render_shards_by_rows(gpu_ready):
     frame = cdist.assemble(torch.from_numpy(np.stack(parts)), H, S, n).numpy()
     assert np.array_equal(frame, full["image"])
     assert full["image"].max() > 0.5
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_photon_pass_random_scenes_vs_oracle(gpu_ready, orc, seed):
+    """Fuzz for row f1: random triangle soups (opaque / mirror / glass, with duplicate and degenerate triangles) and
+    spheres in the box, eye pass + 12 000 photons + gather: the image equals the oracle's serial result bit for bit."""
+    import cgraytracing_amd as cg
+    from test_gpu_parity import _random_mesh
+    rng = np.random.default_rng(500 + seed)
+    objs = scenes.planes(scenes.stone_small_texture(True) if seed == 1 else None)
+    objs.append(scenes.Sphere((-6.0, -14.0, 30.0), 4.0, (1, 1, 1), 0.8, 0.5 if seed != 2 else 0.0))
+    for k in range(2):
+        refl, transp = [(0.0, 0.0), (0.8, 0.5), (0.8, 0.0)][(seed + k) % 3]
+        tri = _random_mesh(rng, int([60, 200, 11][(seed + k) % 3]), rng.uniform((-8, -16, 24), (8, -4, 34)), 7.0, 0.1)
+        objs.append(scenes.TriangleMesh.from_triangles(tri, (0.6, 0.7, 0.8), refl, transp, 0))
+    W, H, spp, nph = 40, 30, 1 + seed % 2, 12000
+    cam = scenes.cam_dof() if seed % 2 else scenes.cam_pinhole()
+    want = BackendScene(orc, objs).ppm(cam, W, H, spp, 5, nphotons=nph)
+    sc = cg.Scene(objs)
+    got = sc.ppm_render(W, H, spp, cam, 5, 12345, nphotons=nph)
+    sc.close()
+    assert got["count"] == want["n"]
+    assert np.array_equal(got["image"], want["image"])
+    assert want["image"].max() > 0.1
