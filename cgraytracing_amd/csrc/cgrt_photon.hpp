@@ -197,37 +197,6 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : 4) void photon_trace_kernel(Dev
     }
 }
 
-// 2. candidate (hitpoint, event) pairs.  One lane per event walks the reference's candidate set: the buckets its 27
-// neighbour cells hash to (hash.h:35-37, main.cpp:107-113) -- cells that collide in the table are deliberately NOT
-// deduplicated, the reference walks such a bucket once per cell.  Output space is reserved with ONE global atomic
-// per workgroup (count pass, LDS scan, write pass): a global atomic per hit serialises on a single address in L2 --
-// measured 13.5 ms per 1.3 M events, 16 ns per wave-level atomic -- and dominated the whole photon pass.
-template <bool WRITE>
-__device__ __forceinline__ unsigned pairs_walk(const double *__restrict__ hp, const int *__restrict__ bstart, HashArgs ha, V3 P,
-                                               V3 n, int s, unsigned long long *__restrict__ keys,
-                                               unsigned int *__restrict__ vals, unsigned pos, unsigned cap) {
-    int ix, iy, iz;
-    ref_coord(P.x, P.y, P.z, ha.celllength, ix, iy, iz);
-    ix -= 1; iy -= 1; iz -= 1;
-    unsigned cnt = 0;
-    for (int c = 0; c < 27; c++) {
-        const unsigned b = ref_hash(ix + c / 9, iy + (c / 3) % 3, iz + c % 3, ha.hashsize);
-        const int i1 = bstart[b + 1];
-        for (int i = bstart[b]; i < i1; i++) {
-            const double *h = hp + 16 * (size_t)i;
-            const V3 dd = mk(h[5], h[6], h[7]) - P;
-            if ((dot(mk(h[8], h[9], h[10]), n) > kEps) && (dot(dd, dd) <= h[14])) {  // main.cpp:116, batch-start r2
-                if (WRITE && pos + cnt < cap) {
-                    keys[pos + cnt] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
-                    vals[pos + cnt] = (unsigned int)s;
-                }
-                cnt++;
-            }
-        }
-    }
-    return cnt;
-}
-
 // Spatial order for the pair search: events keyed by their hash-grid cell (invalid slots last).  Lanes of a wave then
 // probe the same few buckets, so their loads coalesce and hit in L1 instead of being 64 unrelated L2 round trips.
 // Only the ORDER OF THE SEARCH changes; every pair still carries its slot number = serial position.
@@ -250,6 +219,28 @@ __global__ void event_keys_kernel(const double *__restrict__ events, const unsig
     vals[s] = (unsigned)s;
 }
 
+// 2. candidate (hitpoint, event) pairs.  One lane per event walks the reference's candidate set: the buckets its 27
+// neighbour cells hash to (hash.h:35-37, main.cpp:107-113) -- cells that collide in the table are deliberately NOT
+// deduplicated, the reference walks such a bucket once per cell.
+// Hits are staged in a per-wave LDS buffer (the walk is wave-uniform: every lane steps through its bucket together, a
+// ballot hands out buffer slots) and leave for global memory in blocks: space for everything a workgroup still holds at
+// the end is reserved with ONE atomic per workgroup, a wave whose buffer fills up earlier reserves for itself.  A global
+// atomic per hit serialises on a single address in L2 -- measured 16 ns each, 13.5 ms per 1.3 M events -- and dominated
+// the whole photon pass; counting first and writing in a second walk (the previous form) paid for every probe twice.
+constexpr int kPairBuf = 768;  // staged pairs per wave (6 KiB); flushed before an iteration that could overflow it
+
+__device__ __forceinline__ void pairs_flush(const unsigned long long *buf, unsigned cnt, unsigned base,
+                                            unsigned long long *__restrict__ keys, unsigned int *__restrict__ vals, unsigned cap) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned k = lane; k < cnt; k += 64) {
+        const unsigned long long key = buf[k];
+        if (base + k < cap) {
+            keys[base + k] = key;
+            vals[base + k] = (unsigned int)(key & 0xffffffull);  // the slot number is the key's low 24 bits
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restrict__ events,
                                                            const unsigned int *__restrict__ order_keys,
                                                            const unsigned int *__restrict__ order, int nslots, HashArgs ha,
@@ -257,40 +248,69 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
                                                            unsigned long long *__restrict__ keys,
                                                            unsigned int *__restrict__ vals, unsigned int *__restrict__ npairs,
                                                            unsigned int cap) {
-    __shared__ unsigned wave_tot[4], wave_ev[4], block_base;
+    __shared__ unsigned long long stage[4][kPairBuf];
+    __shared__ unsigned wave_cnt[4], wave_ev[4], block_base;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool on = t < nslots && order_keys[t] != kNoEvent;
     const int s = on ? (int)order[t] : 0;
+    unsigned long long *buf = stage[wave];
+    unsigned cnt = 0;  // wave-uniform: pairs staged in buf
     V3 P = mk(0, 0, 0), n = mk(0, 0, 0);
-    unsigned cnt = 0;
+    int ix = 0, iy = 0, iz = 0;
     if (on) {
         const double *e = events + 9 * (size_t)s;
         P = mk(e[0], e[1], e[2]);
         n = mk(e[3], e[4], e[5]);
-        cnt = pairs_walk<false>(hp, bstart, ha, P, n, s, keys, vals, 0u, 0u);
+        ref_coord(P.x, P.y, P.z, ha.celllength, ix, iy, iz);
+        ix -= 1; iy -= 1; iz -= 1;
     }
-    // wave inclusive scan of cnt
-    unsigned inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned v = __shfl_up(inc, d);
-        if (lane >= d) inc += v;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (__ballot(on) != 0ull) {
+        for (int c = 0; c < 27; c++) {
+            int i = 0, i1 = 0;
+            if (on) {
+                const unsigned b = ref_hash(ix + c / 9, iy + (c / 3) % 3, iz + c % 3, ha.hashsize);
+                i = bstart[b];
+                i1 = bstart[b + 1];
+            }
+            while (__ballot(i < i1) != 0ull) {  // all lanes step through their buckets together
+                if (cnt > (unsigned)(kPairBuf - 64)) {  // the next step could overflow: this wave reserves for itself
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(npairs, cnt);
+                    base = __shfl(base, 0);
+                    pairs_flush(buf, cnt, base, keys, vals, cap);
+                    cnt = 0;
+                }
+                bool hit = false;
+                if (i < i1) {
+                    const double *h = hp + 16 * (size_t)i;
+                    const V3 dd = mk(h[5], h[6], h[7]) - P;
+                    hit = (dot(mk(h[8], h[9], h[10]), n) > kEps) && (dot(dd, dd) <= h[14]);  // main.cpp:116, batch-start r2
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) buf[cnt + (unsigned)__popcll(m & lt)] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
+                cnt += (unsigned)__popcll(m);
+                i++;
+            }
+        }
     }
-    if (lane == 63) wave_tot[wave] = inc;
-    const unsigned long long evm = __ballot(on);
-    if (lane == 0) wave_ev[wave] = (unsigned)__popcll(evm);
+    const unsigned nev_wave = (unsigned)__popcll(__ballot(on));
+    if (lane == 0) {
+        wave_cnt[wave] = cnt;
+        wave_ev[wave] = nev_wave;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        const unsigned tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         const unsigned nev = wave_ev[0] + wave_ev[1] + wave_ev[2] + wave_ev[3];
         block_base = tot ? atomicAdd(npairs, tot) : 0u;
         if (nev) atomicAdd(npairs + 1, nev);  // events processed (statistics)
     }
     __syncthreads();
-    unsigned pos = block_base + (inc - cnt);
-    for (int w = 0; w < wave; w++) pos += wave_tot[w];
-    if (on && cnt) pairs_walk<true>(hp, bstart, ha, P, n, s, keys, vals, pos, cap);
+    unsigned base = block_base;
+    for (int w = 0; w < wave; w++) base += wave_cnt[w];
+    pairs_flush(buf, cnt, base, keys, vals, cap);
 }
 
 // 4. ordered replay per hitpoint
