@@ -1,6 +1,6 @@
 """Measurement driver (not a test): Mrays/s of every BASELINE.json configuration on one MI355X, with the CPU
 reference (oracle/_ref, 1 thread) or the oracle port timed on a small crop of the same workload beside it.
-Writes one JSON document to stdout.   python tests/measure_configs.py [--quick]"""
+Writes one JSON document to stdout (and to FILE with --out).   python tests/measure_configs.py [--quick] [--out FILE]"""
 import json
 import os
 import sys
@@ -86,6 +86,10 @@ def main():
                      cpu=c, gpu_over_cpu=round(g["mrays_per_s"] / c["mrays_per_s"], 0))
         doc["configs"].append(entry)
         print(json.dumps(entry), file=sys.stderr, flush=True)
+    # the compiled reference prints progress text to stdout from C; "--out FILE" keeps the document clean
+    if "--out" in sys.argv:
+        with open(sys.argv[sys.argv.index("--out") + 1], "w") as fh:
+            json.dump(doc, fh, indent=1)
     print(json.dumps(doc, indent=1))
 
 
