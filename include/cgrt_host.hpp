@@ -3,7 +3,8 @@
 // Keeps the reference's host-side API surface -- Vec3 (headers/vec3.h), Texture (headers/texture.h), Object /
 // Sphere / Plane / TriangleMesh (headers/objects.h), Bezier (headers/bezier.h) with the SAME constructor
 // signatures, and a render(objs) entry shaped like main.cpp:169 -- so that the scene-building part of a
-// main() written against the reference compiles against this header unchanged.  Nothing is traced on the host:
+// main() written against the reference compiles against this header unchanged.  Nothing is traced on the host
+// (Object::intersect, too, runs on the device):
 // render() flattens `objs` through cgrt_scene_add_* and launches the eye pass on the GPU with
 // cgrt_trace_grid_host().  This file is original code; it mirrors interfaces, not implementations.
 #ifndef CGRT_HOST_HPP
@@ -109,11 +110,24 @@ class Texture {
 class SceneBuilder;
 class Object {
   public:
-    virtual ~Object() {}
+    Object() : probe_(nullptr) {}
+    Object(const Object &) : probe_(nullptr) {}  // a copy builds its own probe scene when first asked
+    Object &operator=(const Object &);           // the assigned-to object's cached probe scene is dropped
+    virtual ~Object();
+    // objects.h:20: nearest intersection of one ray with this object.  Runs ON THE DEVICE (this object alone, committed
+    // once on `intersect_device` and cached; the function-level probe cgrt_intersect_rays) -- there is no host tracer.
+    // len and normalvec are written only on a hit.  For many rays use intersect_batch.
+    bool intersect(const Vec3 &rayorig, const Vec3 &raydir, double &len, Vec3 &normalvec) const;
+    // n rays at once: org3 / dir3 are n x 3 doubles; hit, len, normal3 receive n, n and n x 3 values
+    void intersect_batch(const double *org3, const double *dir3, int n, int32_t *hit, double *len, double *normal3) const;
     virtual double getTransparency() const = 0;
     virtual double getReflection() const = 0;
     virtual Vec3 getSurfaceColor(const Vec3 &) const = 0;  // flat colour; textured lookups happen on the device
     virtual int add_to(SceneBuilder &sb) const = 0;         // appends this object to a cgrt_scene
+    int intersect_device = 0;
+
+  private:
+    mutable SceneBuilder *probe_;
 };
 
 class SceneBuilder {
@@ -136,6 +150,40 @@ class SceneBuilder {
         return id;
     }
 };
+
+inline Object::~Object() { delete probe_; }
+inline Object &Object::operator=(const Object &) {
+    delete probe_;
+    probe_ = nullptr;
+    return *this;
+}
+inline void Object::intersect_batch(const double *org3, const double *dir3, int n, int32_t *hit, double *len,
+                                    double *normal3) const {
+    if (!probe_) {
+        SceneBuilder *sb = new SceneBuilder();
+        try {
+            add_to(*sb);
+            check(cgrt_scene_commit(sb->scene, intersect_device));
+        } catch (...) {
+            delete sb;
+            throw;
+        }
+        probe_ = sb;
+    }
+    check(cgrt_intersect_rays(probe_->scene, 0, org3, dir3, nullptr, n, hit, len, normal3));
+}
+inline bool Object::intersect(const Vec3 &rayorig, const Vec3 &raydir, double &len, Vec3 &normalvec) const {
+    double o[3], d[3], l = 0, nv[3] = {0, 0, 0};
+    int32_t h = 0;
+    rayorig.get(o);
+    raydir.get(d);
+    intersect_batch(o, d, 1, &h, &l, nv);
+    if (h) {
+        len = l;
+        normalvec = Vec3(nv[0], nv[1], nv[2]);
+    }
+    return h != 0;
+}
 
 // Sphere(c, r, sc, refl, transp, ec)   objects.h:28-38
 class Sphere : public Object {

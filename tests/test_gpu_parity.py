@@ -4,6 +4,8 @@ Bar (BASELINE.json): ray and hitpoint counts identical; per-pixe
 oracle's fp64 sum scaled by 1/spp and rounded to fp32.  The kernels use the reference's operation order in
 fp64 without FMA contraction, so the comparison is made at 1e-6 absolute (fp32 rounding of values <= ~2), far
 inside the 1e-4 tolerance the north star states; the exact-equality fraction is reported too."""
+import os
+
 import numpy as np
 import pytest
 
@@ -374,3 +376,39 @@ def test_random_scenes_match_oracle_exactly(gpu_ready, orc, seed):
     assert got["nrays"] == want["nrays"]
     assert np.array_equal(got["nhit"], want["nhit"])
     assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
+
+
+@pytest.mark.parametrize("which", ["sphere", "plane", "mesh", "vase"])
+def test_cpp_object_intersect_matches_oracle(gpu_ready, orc, which):
+    """Object::intersect / intersect_batch of include/cgrt_host.hpp -- the reference's virtual (objects.h:20) -- called from
+    a plain C++ program (tests/native/host_intersect.cpp) on the same objects the oracle builds: hit flags, distances
+    and normals identical bit for bit (Bezier: the statistical bar of DESIGN.md section 2)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cgraytracing_amd", "cgrt_host_intersect")
+    assert os.path.exists(exe), "build it with make -C cgraytracing_amd/csrc all"
+    mesh_file = os.path.join(GOLD, "assets", "mesh_t0.txt")
+    obj = {"sphere": lambda: scenes.Sphere((-8.0, -13.0, 25), 7, (1.0, 1.0, 1.0), 0.8, 0.5),
+           "plane": lambda: scenes.Plane((0.0, -20, 0), (0, 1, 0), (0.15, 0.15, 0.15), 0.0, 0.0),
+           "mesh": lambda: scenes.TriangleMesh(mesh_file, 3.0, (1.0, -4.0, 30.0), (0.6, 0.7, 0.9), 0.8, 0.5, 0),
+           "vase": scenes.vase_bezier}[which]()
+    rng = np.random.default_rng(17)
+    n = 600
+    o = np.tile(np.array([0.0, 0.0, -10.0]), (n, 1)) + rng.normal(0, 0.5, (n, 3))
+    target = {"sphere": (-8.0, -13.0, 25.0), "plane": (0.0, -20.0, 30.0), "mesh": (1.0, -4.0, 30.0), "vase": (15.0, -10.0, 35.0)}[which]
+    d = np.asarray(target) + rng.normal(0, 4.0, (n, 3)) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    text = "\n".join("%.17g %.17g %.17g %.17g %.17g %.17g" % tuple(np.concatenate([o[i], d[i]])) for i in range(n))
+    args = [exe, which] + ([mesh_file] if which == "mesh" else [])
+    out = subprocess.run(args, input=text, capture_output=True, text=True, check=True).stdout
+    got = np.array([[float(x) for x in line.split()] for line in out.strip().splitlines()])
+    hw, lw, nw = BackendScene(orc, [obj]).intersect_batch(0, o, d, keys=np.zeros(n, np.uint64) if which == "vase" else None)
+    assert got.shape == (n, 5) and hw.sum() > 50
+    if which == "vase":
+        agree = (got[:, 0] == hw)
+        close = np.abs(got[:, 1] - lw)[agree & (hw != 0)] < 1e-6
+        assert agree.mean() >= 0.995 and close.mean() >= 0.99
+        return
+    assert np.array_equal(got[:, 0], hw)
+    m = hw != 0
+    assert np.array_equal(got[m, 1], lw[m]) and np.array_equal(got[m, 2:], nw[m])
