@@ -530,9 +530,12 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     // ---- photons, in batches ----
     tm.start();
     int batch = ph->batch > 0 ? (ph->batch < (1 << 20) ? ph->batch : (1 << 20)) : (1 << 20);
+    const int batch_max = batch;
     const int nslots_max = batch * kSegStride;
     DevBuf ev, valid, pk0, pk1, pv0, pv1, npairs, ek0, ek1, eo0, eo1;
-    const unsigned pair_cap = 1u << 27;  // 128 M pairs per batch (3 GiB of keys and values); a batch that overflows is halved
+    // pairs per batch: room for 128 per hitpoint, between 4 M and 128 M (3 GiB of keys and values); a batch that overflows is halved
+    const unsigned long long want_cap = (unsigned long long)n * 128ull;
+    const unsigned pair_cap = (unsigned)(want_cap < (1ull << 22) ? (1ull << 22) : (want_cap > (1ull << 27) ? (1ull << 27) : want_cap));
     HIP_TRY(ev.alloc((size_t)nslots_max * 9 * sizeof(double)));
     HIP_TRY(valid.alloc((size_t)nslots_max));
     HIP_TRY(pk0.alloc((size_t)pair_cap * 8)); HIP_TRY(pk1.alloc((size_t)pair_cap * 8));
@@ -574,6 +577,7 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
         }
         first += pa.count;
         out->n_events += np2[1];
+        if (batch < batch_max && np < pair_cap / 4) batch *= 2;  // radii shrink as photons arrive: later batches hold fewer pairs
         if (np == 0) continue;
         out->n_pairs += np;
         rc = sort_pairs(pk0.as<unsigned long long>(), pk1.as<unsigned long long>(), pv0.as<unsigned int>(), pv1.as<unsigned int>(), np,
