@@ -55,8 +55,12 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
     }
     __syncthreads();
 
+    // which tile, and -- when a tile's samples are split over several workgroups -- which chunk of its samples
+    const int tile_blocks = (int)gridDim.x / g.chunks;
+    const int chunk = (int)blockIdx.x / tile_blocks;
     int tile_x, tile_y;
-    if (!tile_of_block(g, tile_x, tile_y)) return;  // whole workgroup (after the barrier above; no further barrier is missed)
+    if (!tile_of_block(g, (int)blockIdx.x % tile_blocks, tile_x, tile_y)) return;  // whole workgroup (no later barrier is missed)
+    const int s_end = (g.chunks > 1) ? ((chunk + 1) * g.chunk_spp < g.spp ? (chunk + 1) * g.chunk_spp : g.spp) : g.spp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // wave = 16x4 pixels, 2x2 waves per workgroup (8x8 per wave measured: meshes equal, C2 7 % slower)
     const int lx = (wave & 1) * 16 + (lane & 15);
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
     bool sib_valid = false;
     unsigned char *lslot = lds_raw;  // level L, field f of this thread: lslot + L*kLevelBytes + (f*256 + tid)*8
     int sp = 0;
-    int s = 0;  // next sample to start
+    int s = (g.chunks > 1) ? chunk * g.chunk_spp : 0;  // next sample to start
     bool have = false;
     V3 o = camorg, d = pdir, adj = mk(1, 1, 1);
     int depth_left = 0;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
 
     while (true) {
         if (!have) {
-            if (live && s < g.spp) {
+            if (live && s < s_end) {
                 // start the next sample of this lane's pixel (main.cpp:204-209)
                 k_smp = sample_key(k_pix, (uint64_t)(g.sample_offset + s));
                 if (DOF) {
@@ -261,6 +265,16 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
         }
     }
 
+    if (g.chunks > 1) {
+        // split samples: this workgroup's raw fp64 sums; finalize_chunks_kernel adds the chunks in order
+        if ((w < g.W) && (j < g.rows)) {  // rows past the image (stripe padding) carry zero sums
+            const size_t px = ((size_t)chunk * g.rows + (size_t)j) * g.W + (size_t)w;
+            g.partial[3 * px + 0] = acc_r;
+            g.partial[3 * px + 1] = acc_g;
+            g.partial[3 * px + 2] = acc_b;
+            if (g.partial_nhit) g.partial_nhit[px] = my_hits;
+        }
+    } else {
     // ---- coalesced store through LDS: 32 px x 3 floats = 384 contiguous bytes per tile row ----
     if (GLASS) __syncthreads();  // every wave is done with the pending-ray levels the tile aliases
     ltile[ly * (kTileW * 3) + lx * 3 + 0] = (float)(acc_r * g.inv_spp_total);
@@ -277,6 +291,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
         }
     }
     if (nhit_out && (w < g.W) && (j < g.rows)) nhit_out[(size_t)j * g.W + w] = my_hits;
+    }
 
     if (counters) {
         // wave reduction, then one atomic per wave and counter
@@ -299,6 +314,30 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
             }
         }
     }
+}
+
+// CGRT_GRID_SPLIT_SAMPLES, second step: chunk sums added in chunk order, scaled, rounded once to fp32.
+__global__ void finalize_chunks_kernel(GridParams g, float *__restrict__ rgb, uint32_t *__restrict__ nhit_out) {
+    const size_t npx = (size_t)g.rows * g.W;
+    const size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= npx) return;
+    double r = 0, gg = 0, b = 0;
+    uint32_t hits = 0;
+    for (int c = 0; c < g.chunks; c++) {
+        const size_t q = (size_t)c * npx + px;
+        r += g.partial[3 * q + 0];
+        gg += g.partial[3 * q + 1];
+        b += g.partial[3 * q + 2];
+        if (g.partial_nhit) hits += g.partial_nhit[q];
+    }
+    const float fr = (float)(r * g.inv_spp_total), fg = (float)(gg * g.inv_spp_total), fb = (float)(b * g.inv_spp_total);
+    float *dst = rgb + 3 * px;
+    if (g.accumulate) {
+        dst[0] += fr; dst[1] += fg; dst[2] += fb;
+    } else {
+        dst[0] = fr; dst[1] = fg; dst[2] = fb;
+    }
+    if (nhit_out) nhit_out[px] = hits;
 }
 
 // function-level probe: one object, n rays (cgrt_intersect_rays)

@@ -11,6 +11,11 @@ struct GridParams {
     int32_t spp, sample_offset, max_depth;
     int32_t accumulate;  // CGRT_GRID_ACCUMULATE: rgb += this pass (nhit is overwritten)
     int32_t xcd_tiles;   // block -> tile mapping: 1 = XCD-aware super-tiles, 0 = row-major (see tile_of_block)
+    // CGRT_GRID_SPLIT_SAMPLES: chunks > 1 workgroups per tile, workgroup c of a tile takes samples [c*chunk_spp, ...) and
+    // leaves its raw fp64 sums in partial[c][local pixel][3] (and its hit count in partial_nhit[c][local pixel])
+    int32_t chunks, chunk_spp;
+    double *partial;
+    uint32_t *partial_nhit;
     double inv_spp_total;
     uint64_t seed;
     double cam[3], half_width, focus_plane, lens_radius;
@@ -60,9 +65,8 @@ __host__ __device__ inline int tile_grid_blocks(int W, int rows, bool xcd_tiles)
     return ((nsuper + kXcds - 1) / kXcds) * kXcds * kSuperTiles;
 }
 // false: this block has no tile (edge of the super-tile grid)
-__device__ __forceinline__ bool tile_of_block(const GridParams &g, int &tile_x, int &tile_y) {
+__device__ __forceinline__ bool tile_of_block(const GridParams &g, int b, int &tile_x, int &tile_y) {
     const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
-    const int b = (int)blockIdx.x;
     if (!g.xcd_tiles) {
         tile_x = b % tiles_x;
         tile_y = b / tiles_x;

@@ -47,6 +47,10 @@ struct cgrt_scene {
     std::vector<void *> allocs;
     int64_t device_bytes = 0;
     std::vector<int> tree_of;  // flat tree list (object order)
+    // CGRT_GRID_SPLIT_SAMPLES: chunk sums between the two kernels; grown on demand, reused by later launches on this handle
+    // (launches on one handle are stream-ordered by the caller, see cgrt.h "Threading")
+    mutable void *scratch = nullptr;
+    mutable size_t scratch_bytes = 0;
 };
 
 static thread_local std::string g_err;
@@ -93,6 +97,7 @@ void cgrt_scene_destroy(cgrt_scene *s) {
         if (hipGetDevice(&cur) == hipSuccess) {
             (void)hipSetDevice(s->device);
             for (void *p : s->allocs) (void)hipFree(p);
+            if (s->scratch) (void)hipFree(s->scratch);
             (void)hipSetDevice(cur);
         }
     }
@@ -369,7 +374,25 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.lens_radius = cam->lens_radius;
 
     g.xcd_tiles = (s->dev.has_mesh && !s->dev.has_bezier) ? 1 : 0;
-    const dim3 grid_dim((unsigned)tile_grid_blocks(g.W, g.rows, g.xcd_tiles != 0)), block(kThreads);
+    // Split a tile's samples over several workgroups (CGRT_GRID_SPLIT_SAMPLES, and always with a Bezier object: the few
+    // tiles over it carry nearly all the work -- measured 1.2 of 3 wave slots per SIMD occupied on a C5 band -- and their
+    // parity is statistical in any case): chunks of >= 16 samples, at most 16 chunks, at most 4 GiB of chunk sums.
+    g.chunks = 1;
+    g.chunk_spp = grid->spp;
+    g.partial = nullptr;
+    g.partial_nhit = nullptr;
+    const size_t npx_all = (size_t)grid->rows * grid->width;
+    if (((grid->flags & CGRT_GRID_SPLIT_SAMPLES) || s->dev.has_bezier) && grid->spp >= 32) {
+        int chunks = grid->spp / 16;
+        if (chunks > 16) chunks = 16;
+        while (chunks > 1 && (size_t)chunks * npx_all * 28 > ((size_t)4 << 30)) chunks--;
+        if (chunks > 1) {
+            g.chunk_spp = (grid->spp + chunks - 1) / chunks;
+            g.chunks = (grid->spp + g.chunk_spp - 1) / g.chunk_spp;
+        }
+    }
+    const int tile_blocks = tile_grid_blocks(g.W, g.rows, g.xcd_tiles != 0);
+    const dim3 grid_dim((unsigned)(tile_blocks * g.chunks)), block(kThreads);
     size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
@@ -380,6 +403,21 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0, bez = s->dev.has_bezier != 0;
     const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
     const bool stats = (grid->flags & CGRT_GRID_STATS) != 0 && trees && !bez;
+    if (g.chunks > 1) {
+        const size_t need = (size_t)g.chunks * npx_all * (3 * sizeof(double) + sizeof(uint32_t));
+        if (s->scratch_bytes < need) {
+            if (s->scratch) (void)hipFree(s->scratch);
+            s->scratch = nullptr;
+            s->scratch_bytes = 0;
+            if (hipMalloc(&s->scratch, need) != hipSuccess) {
+                if (caller_dev != s->device) (void)hipSetDevice(caller_dev);
+                return fail(CGRT_ERR_DEVICE, "split samples: cannot allocate the chunk sums");
+            }
+            s->scratch_bytes = need;
+        }
+        g.partial = reinterpret_cast<double *>(s->scratch);
+        g.partial_nhit = nhit ? reinterpret_cast<uint32_t *>(g.partial + (size_t)g.chunks * npx_all * 3) : nullptr;
+    }
     lds += glass ? kStackBytes : kTileBytes;
     if (bez) lds += (kThreads / 64) * sizeof(BezLds);
     if (trees && s->dev.cached_tree >= 0) lds += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
@@ -401,6 +439,8 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     }
 #undef LAUNCH_DG
 #undef LAUNCH
+    if (g.chunks > 1)
+        hipLaunchKernelGGL(finalize_chunks_kernel, dim3((unsigned)((npx_all + 255) / 256)), dim3(256), 0, st, g, rgb, nhit);
     const hipError_t launch_err = hipGetLastError();
     if (caller_dev != s->device) (void)hipSetDevice(caller_dev);
     if (launch_err != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(launch_err));
@@ -433,6 +473,7 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     g.seed = grid->seed;
     for (int k = 0; k < 3; k++) g.cam[k] = cam->cam[k];
     g.half_width = cam->half_width; g.focus_plane = cam->focus_plane; g.lens_radius = cam->lens_radius;
+    g.chunks = 1; g.chunk_spp = grid->spp; g.partial = nullptr; g.partial_nhit = nullptr;  // capture keeps one workgroup per tile
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_rec, b_cnt;
     HIP_TRY(b_rgb.alloc(npx * 3 * sizeof(float)));

@@ -68,9 +68,15 @@ typedef struct cgrt_grid {
 
 enum {
     CGRT_GRID_STATS = 1,      /* also count tree-node and triangle tests (CGRT_CNT_NODE_TESTS / _TRI_TESTS)          */
-    CGRT_GRID_ACCUMULATE = 2  /* rgb += this pass instead of rgb = this pass: progressive multi-pass rendering with
+    CGRT_GRID_ACCUMULATE = 2, /* rgb += this pass instead of rgb = this pass: progressive multi-pass rendering with
                                  sample_offset / spp_total, the fp32 replacement for the reference's average.cpp,
                                  which averages nine uint8 images with truncating division (average.cpp:21-64)     */
+    CGRT_GRID_SPLIT_SAMPLES = 4 /* let several workgroups share a tile's samples: each sums a contiguous chunk of the
+                                 samples in fp64 and the chunk sums are added in chunk order by a second kernel.
+                                 Reproducible, but the fp64 summation ORDER differs from the sample-by-sample sum
+                                 (the last bit of a sum may differ before the rounding to fp32).  It fills the GPU
+                                 when a few tiles carry most of the work.  Scenes with a Bezier object -- whose
+                                 parity is statistical anyway -- always render this way.      */
 };
 
 /* indices into the uint64 counters[CGRT_NCOUNTERS] array written by cgrt_trace_grid (added to, not reset) */
