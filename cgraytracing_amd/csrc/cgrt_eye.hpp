@@ -22,20 +22,21 @@ struct HitpointSink {
     unsigned long long cap;
 };
 
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false>
-__global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256>
+__global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters,
                                                              HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
+    using TG = TileGeom<NT>;
     // LDS carve-up: [ pending-ray levels (GLASS) -- aliased by the output tile at the end | objs ]
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float *ltile = reinterpret_cast<float *>(lds_raw);
-    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? kStackBytes : kTileBytes));  // n_objs records
+    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? TG::stack_bytes : TG::tile_bytes));  // n_objs records
     // BEZ: one BezLds per wave behind the object list (16-byte aligned: ObjRec is 128 B)
     unsigned char *lrest = reinterpret_cast<unsigned char *>(lobjs + sc.n_objs);
     LdsAux aux;
     aux.bl = BEZ ? reinterpret_cast<volatile BezLds *>(lrest) + (threadIdx.x >> 6) : nullptr;
-    if (BEZ) lrest += (kThreads / 64) * sizeof(BezLds);
+    if (BEZ) lrest += (NT / 64) * sizeof(BezLds);
     // TREES: node cache behind that (32-byte records, region is 16-byte aligned)
     NodeRec *lnodes = reinterpret_cast<NodeRec *>(lrest);
     aux.lnodes = (TREES && sc.cached_tree >= 0) ? lnodes : nullptr;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes + sc.trees[sc.cached_tree].node_begin);
         uint4 *dst = reinterpret_cast<uint4 *>(lnodes);
         const int n16 = sc.cached_nodes * (int)(sizeof(NodeRec) / 16);
-        for (int k = threadIdx.x; k < n16; k += kThreads) dst[k] = src[k];
+        for (int k = threadIdx.x; k < n16; k += NT) dst[k] = src[k];
     }
 
     // stage the primitive list in LDS (128 B records, copied as 16-byte pieces)
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.objs);
         uint4 *dst = reinterpret_cast<uint4 *>(lobjs);
         const int n16 = sc.n_objs * (int)(sizeof(ObjRec) / 16);
-        for (int k = threadIdx.x; k < n16; k += kThreads) dst[k] = src[k];
+        for (int k = threadIdx.x; k < n16; k += NT) dst[k] = src[k];
     }
     __syncthreads();
 
@@ -59,14 +60,14 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
     const int tile_blocks = (int)gridDim.x / g.chunks;
     const int chunk = (int)blockIdx.x / tile_blocks;
     int tile_x, tile_y;
-    if (!tile_of_block(g, (int)blockIdx.x % tile_blocks, tile_x, tile_y)) return;  // whole workgroup (no later barrier is missed)
+    if (!tile_of_block(g, (int)blockIdx.x % tile_blocks, tile_x, tile_y, TG::W, TG::H)) return;  // whole workgroup (no later barrier is missed)
     const int s_end = (g.chunks > 1) ? ((chunk + 1) * g.chunk_spp < g.spp ? (chunk + 1) * g.chunk_spp : g.spp) : g.spp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // wave = 16x4 pixels, 2x2 waves per workgroup (8x8 per wave measured: meshes equal, C2 7 % slower)
     const int lx = (wave & 1) * 16 + (lane & 15);
     const int ly = (wave >> 1) * 4 + (lane >> 4);
-    const int w = tile_x * kTileW + lx;
-    const int j = tile_y * kTileH + ly;  // local row
+    const int w = tile_x * TG::W + lx;
+    const int j = tile_y * TG::H + ly;  // local row
     const int h = global_row(g, j);
     const bool live = (w < g.W) && (j < g.rows) && (h < g.H);
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
     Pending deep[2];   // third stack level (scratch; indexed dynamically so that it stays out of registers)
     Pending sib;       // refracted sibling of a leaf-level glass hit (registers)
     bool sib_valid = false;
-    unsigned char *lslot = lds_raw;  // level L, field f of this thread: lslot + L*kLevelBytes + (f*256 + tid)*8
+    unsigned char *lslot = lds_raw;  // level L, field f of this thread: lslot + L*TG::level_bytes + (f*256 + tid)*8
     int sp = 0;
     int s = (g.chunks > 1) ? chunk * g.chunk_spp : 0;  // next sample to start
     bool have = false;
@@ -209,13 +210,13 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
                                 sib_valid = true;
                             } else {
                                 if (sp < kLdsLevels) {
-                                    double *q = reinterpret_cast<double *>(lslot + sp * kLevelBytes) + threadIdx.x;
-                                    q[0 * kThreads] = pe.o.x; q[1 * kThreads] = pe.o.y; q[2 * kThreads] = pe.o.z;
-                                    q[3 * kThreads] = pe.d.x; q[4 * kThreads] = pe.d.y; q[5 * kThreads] = pe.d.z;
-                                    q[6 * kThreads] = pe.adj.x; q[7 * kThreads] = pe.adj.y; q[8 * kThreads] = pe.adj.z;
+                                    double *q = reinterpret_cast<double *>(lslot + sp * TG::level_bytes) + threadIdx.x;
+                                    q[0 * NT] = pe.o.x; q[1 * NT] = pe.o.y; q[2 * NT] = pe.o.z;
+                                    q[3 * NT] = pe.d.x; q[4 * NT] = pe.d.y; q[5 * NT] = pe.d.z;
+                                    q[6 * NT] = pe.adj.x; q[7 * NT] = pe.adj.y; q[8 * NT] = pe.adj.z;
                                     // depth_left <= 4 and path < 32: one word
-                                    reinterpret_cast<uint32_t *>(lslot + sp * kLevelBytes +
-                                                                 kPendDoubles * kThreads * sizeof(double))[threadIdx.x] =
+                                    reinterpret_cast<uint32_t *>(lslot + sp * TG::level_bytes +
+                                                                 kPendDoubles * NT * sizeof(double))[threadIdx.x] =
                                         ((uint32_t)pe.depth_left << 8) | pe.path;
                                 } else {
                                     deep[sp - kLdsLevels] = pe;
@@ -244,12 +245,12 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
             if (GLASS && !have && sp > 0) {
                 --sp;
                 if (sp < kLdsLevels) {
-                    const double *q = reinterpret_cast<const double *>(lslot + sp * kLevelBytes) + threadIdx.x;
-                    o = mk(q[0 * kThreads], q[1 * kThreads], q[2 * kThreads]);
-                    d = mk(q[3 * kThreads], q[4 * kThreads], q[5 * kThreads]);
-                    adj = mk(q[6 * kThreads], q[7 * kThreads], q[8 * kThreads]);
+                    const double *q = reinterpret_cast<const double *>(lslot + sp * TG::level_bytes) + threadIdx.x;
+                    o = mk(q[0 * NT], q[1 * NT], q[2 * NT]);
+                    d = mk(q[3 * NT], q[4 * NT], q[5 * NT]);
+                    adj = mk(q[6 * NT], q[7 * NT], q[8 * NT]);
                     const uint32_t meta = reinterpret_cast<const uint32_t *>(
-                        lslot + sp * kLevelBytes + kPendDoubles * kThreads * sizeof(double))[threadIdx.x];
+                        lslot + sp * TG::level_bytes + kPendDoubles * NT * sizeof(double))[threadIdx.x];
                     depth_left = (int)(meta >> 8);
                     path = meta & 0xffu;
                 } else {
@@ -277,16 +278,16 @@ __global__ __launch_bounds__(kThreads, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) voi
     } else {
     // ---- coalesced store through LDS: 32 px x 3 floats = 384 contiguous bytes per tile row ----
     if (GLASS) __syncthreads();  // every wave is done with the pending-ray levels the tile aliases
-    ltile[ly * (kTileW * 3) + lx * 3 + 0] = (float)(acc_r * g.inv_spp_total);
-    ltile[ly * (kTileW * 3) + lx * 3 + 1] = (float)(acc_g * g.inv_spp_total);
-    ltile[ly * (kTileW * 3) + lx * 3 + 2] = (float)(acc_b * g.inv_spp_total);
+    ltile[ly * (TG::W * 3) + lx * 3 + 0] = (float)(acc_r * g.inv_spp_total);
+    ltile[ly * (TG::W * 3) + lx * 3 + 1] = (float)(acc_g * g.inv_spp_total);
+    ltile[ly * (TG::W * 3) + lx * 3 + 2] = (float)(acc_b * g.inv_spp_total);
     __syncthreads();
-    for (int k = threadIdx.x; k < kTileH * kTileW * 3; k += kThreads) {
-        const int row = k / (kTileW * 3), col = k % (kTileW * 3);
-        const int jj = tile_y * kTileH + row;
-        const int ww = tile_x * kTileW + col / 3;
+    for (int k = threadIdx.x; k < TG::H * TG::W * 3; k += NT) {
+        const int row = k / (TG::W * 3), col = k % (TG::W * 3);
+        const int jj = tile_y * TG::H + row;
+        const int ww = tile_x * TG::W + col / 3;
         if (jj < g.rows && ww < g.W) {
-            float *dst = rgb + ((size_t)jj * g.W + tile_x * kTileW) * 3 + col;
+            float *dst = rgb + ((size_t)jj * g.W + tile_x * TG::W) * 3 + col;
             *dst = g.accumulate ? *dst + ltile[k] : ltile[k];  // progressive passes add into the fp32 frame
         }
     }

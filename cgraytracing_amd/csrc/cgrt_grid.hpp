@@ -57,16 +57,31 @@ __device__ __forceinline__ int global_row(const GridParams &g, int j) {
 // Bezier vase 8.1 -> 9.0 ms -- scenes with no tree to share, whose expensive tiles (glass sphere, vase) then sit on
 // one or two XCDs.  So the launch picks it for scenes with meshes and no Bezier object, row-major otherwise.
 static constexpr int kXcds = 8, kSuperW = 4, kSuperH = 4, kSuperTiles = kSuperW * kSuperH;
-__host__ __device__ inline int tile_grid_blocks(int W, int rows, bool xcd_tiles) {
-    const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH;
+// Workgroup shapes.  NT = 256: four waves on a 32x8-pixel tile (2x2 sub-tiles of 16x4).  NT = 64: ONE wave on a 16x4 tile --
+// a workgroup's wave slots and LDS are only handed on when its LAST wave retires, so with four very unequal waves (a
+// Bezier vase covering part of a tile: a wave over it works ~100x longer than its neighbours) slots idle; with one wave
+// per workgroup every slot is reused the moment its wave ends.
+template <int NT>
+struct TileGeom {
+    static_assert(NT == 256 || NT == 64, "workgroup = 4 waves or 1 wave");
+    static constexpr int W = NT == 256 ? 32 : 16, H = NT == 256 ? 8 : 4;
+    static constexpr size_t level_bytes = (size_t)NT * (kPendDoubles * sizeof(double) + sizeof(uint32_t));
+    static constexpr size_t stack_bytes = (size_t)kLdsLevels * level_bytes;
+    static constexpr size_t tile_bytes = (size_t)W * H * 3 * sizeof(float);
+};
+static_assert(TileGeom<256>::level_bytes == kLevelBytes && TileGeom<256>::tile_bytes == kTileBytes, "TileGeom<256>");
+
+__host__ __device__ inline int tile_grid_blocks(int W, int rows, bool xcd_tiles, int tile_w = kTileW, int tile_h = kTileH) {
+    const int tiles_x = (W + tile_w - 1) / tile_w, tiles_y = (rows + tile_h - 1) / tile_h;
     if (!xcd_tiles) return tiles_x * tiles_y;
     const int sx = (tiles_x + kSuperW - 1) / kSuperW, sy = (tiles_y + kSuperH - 1) / kSuperH;
     const int nsuper = sx * sy;
     return ((nsuper + kXcds - 1) / kXcds) * kXcds * kSuperTiles;
 }
 // false: this block has no tile (edge of the super-tile grid)
-__device__ __forceinline__ bool tile_of_block(const GridParams &g, int b, int &tile_x, int &tile_y) {
-    const int tiles_x = (g.W + kTileW - 1) / kTileW, tiles_y = (g.rows + kTileH - 1) / kTileH;
+__device__ __forceinline__ bool tile_of_block(const GridParams &g, int b, int &tile_x, int &tile_y, int tile_w = kTileW,
+                                              int tile_h = kTileH) {
+    const int tiles_x = (g.W + tile_w - 1) / tile_w, tiles_y = (g.rows + tile_h - 1) / tile_h;
     if (!g.xcd_tiles) {
         tile_x = b % tiles_x;
         tile_y = b / tiles_x;

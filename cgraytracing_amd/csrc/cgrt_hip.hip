@@ -391,8 +391,11 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
             g.chunks = (grid->spp + g.chunk_spp - 1) / g.chunk_spp;
         }
     }
-    const int tile_blocks = tile_grid_blocks(g.W, g.rows, g.xcd_tiles != 0);
-    const dim3 grid_dim((unsigned)(tile_blocks * g.chunks)), block(kThreads);
+    // Bezier scenes run one-wave workgroups on 16x4 tiles (TileGeom<64>): waves over the vase outlast their neighbours ~100x
+    const bool one_wave = s->dev.has_bezier != 0;
+    const int tile_blocks = one_wave ? tile_grid_blocks(g.W, g.rows, false, TileGeom<64>::W, TileGeom<64>::H)
+                                     : tile_grid_blocks(g.W, g.rows, g.xcd_tiles != 0);
+    const dim3 grid_dim((unsigned)(tile_blocks * g.chunks)), block(one_wave ? 64 : kThreads);
     size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
@@ -418,8 +421,8 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         g.partial = reinterpret_cast<double *>(s->scratch);
         g.partial_nhit = nhit ? reinterpret_cast<uint32_t *>(g.partial + (size_t)g.chunks * npx_all * 3) : nullptr;
     }
-    lds += glass ? kStackBytes : kTileBytes;
-    if (bez) lds += (kThreads / 64) * sizeof(BezLds);
+    if (one_wave) lds += (glass ? TileGeom<64>::stack_bytes : TileGeom<64>::tile_bytes) + sizeof(BezLds);
+    else lds += glass ? kStackBytes : kTileBytes;
     if (trees && s->dev.cached_tree >= 0) lds += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
 #define LAUNCH(T, B, D, G, P, S) \
     hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
@@ -429,7 +432,11 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         else     { if (glass) LAUNCH(T, B, false, true, P, S); else LAUNCH(T, B, false, false, P, S); } \
     } while (0)
     if (bez) {  // Bezier scenes share the tree-capable variants (the tree code is skipped when there is no tree)
-        LAUNCH_DG(true, true, false, false);
+#define LAUNCH1(D, G) \
+    hipLaunchKernelGGL((trace_grid_kernel<true, true, D, G, false, false, false, 64>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
+        if (dof) { if (glass) LAUNCH1(true, true); else LAUNCH1(true, false); }
+        else     { if (glass) LAUNCH1(false, true); else LAUNCH1(false, false); }
+#undef LAUNCH1
     } else if (trees) {
         if (stats) LAUNCH_DG(true, false, false, true); else LAUNCH_DG(true, false, false, false);
     } else if (s->dev.all_spheres) {
