@@ -48,7 +48,7 @@ struct cgrt_scene {
     int64_t device_bytes = 0;
     std::vector<int> tree_of;  // flat tree list (object order)
     // CGRT_GRID_SPLIT_SAMPLES: chunk sums between the two kernels; grown on demand, reused by later launches on this handle
-    // (launches on one handle are stream-ordered by the caller, see cgrt.h "Threading")
+    // (launches on one handle are ordered by the caller: cgrt.h, "Threading")
     mutable void *scratch = nullptr;
     mutable size_t scratch_bytes = 0;
 };

@@ -15,6 +15,8 @@
  * Conventions: plain C, no C++ or torch types.  Every function returns CGRT_OK (0) or a negative error code
  * and never exits or throws; cgrt_last_error() gives the message for the calling thread.  Object handles are
  * not thread-safe; distinct scenes may be used concurrently from different host threads / devices.
+ * Threading: launches on ONE scene handle must be ordered by the caller (same stream, or events between streams) --
+ * a handle owns device scratch that consecutive launches reuse (CGRT_GRID_SPLIT_SAMPLES chunk sums).
  * All geometry is IEEE double, like the reference (Vec3 = 3 x double, vec3.h:11-30).
  */
 #ifndef CGRT_H
