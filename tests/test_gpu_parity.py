@@ -351,7 +351,7 @@ def _random_mesh(rng, ntri, center, size, dup_frac):
     return np.asarray(tris, np.float64)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CGRT_FUZZ_SEEDS", "12"))))
 def test_random_scenes_match_oracle_exactly(gpu_ready, orc, seed):
     """Fuzz: random triangle soups (duplicates, shared edges, degenerate triangles; 1 to ~400 triangles, so trees from a
     single leaf to several levels) as opaque, mirror and glass objects, plus random spheres, inside the reference's box of

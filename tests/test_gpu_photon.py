@@ -193,7 +193,7 @@ def test_ppm_render_shards_by_rows(gpu_ready):
     assert full["image"].max() > 0.5
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CGRT_FUZZ_SEEDS", "3"))))
 def test_photon_pass_random_scenes_vs_oracle(gpu_ready, orc, seed):
     """Fuzz for row f1: random triangle soups (opaque / mirror / glass, with duplicate and degenerate triangles) and
     spheres in the box, eye pass + 12 000 photons + gather: the image equals the oracle's serial result bit for bit."""
