@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=24, help="spp of the CPU baseline sample (0 = skip); 24 = about 10 s on one core")
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--check", action="store_true", help="verify a crop of the frame against the oracle")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary single-frame measurements")
