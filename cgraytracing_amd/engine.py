@@ -79,6 +79,13 @@ class Scene:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # ---- introspection ----
     def stats(self):
         st = _capi.SceneStats()
