@@ -156,3 +156,27 @@ def test_edge_cases(gpu_ready, orc):
     want = BackendScene(orc, objs).trace_grid(cam, 160, 120, 2, 5, 9)
     assert got["nrays"] == want["nrays"] and np.array_equal(got["rgb"], to_acc32(want["acc_sum"], 2))
     sc.close()
+
+
+def test_reference_main_configuration_properties(gpu_ready, orc):
+    """Rows f1/f2 at the reference's committed size (main.cpp:28-29,292,320,348-353: 1024x768, spp 1, planes + stone-sized
+    bump floor + diffuse dragon) with 2 M of its 20.48 M photons: size-independent properties -- one hitpoint per pixel
+    (every primary ray ends on a diffuse surface of the closed box), five diffuse hits for all but a handful of photons, a row band rendered
+    on its own equals the same rows of the full frame bit for bit, the tone-mapped bytes are the reference gammaCorr of
+    the gathered image, and the first 20 000 photons alone give the oracle's serial image bit for bit."""
+    import cgraytracing_amd as cg
+    tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    objs = scenes.planes(tex) + [scenes.TriangleMesh.from_triangles(scenes.dragon_tris(), (0.25, 0.25, 0.5), 0.0, 0.0, 1)]
+    W, H, nph = 1024, 768, 2000000
+    cam = scenes.cam_pinhole()
+    with cg.Scene(objs) as sc:
+        full = sc.ppm_render(W, H, 1, cam, 5, 12345, nphotons=nph, want_rgb8=True)
+        band = sc.ppm_render(W, H, 1, cam, 5, 12345, nphotons=nph, rows=64, row_offset=200)
+        small = sc.ppm_render(W, H, 1, cam, 5, 12345, nphotons=20000)
+    assert full["count"] == W * H
+    assert 5 * nph - 1000 < full["n_events"] <= 5 * nph  # a handful of photons leave through a seam of the box
+    assert np.array_equal(band["image"], full["image"][200:264])
+    assert np.array_equal(full["rgb8"], orc.tonemap(full["image"]))
+    assert 0.05 < full["image"].mean() < 1.0 and full["rgb8"][:40].max() == 255  # the ceiling light saturates
+    want = BackendScene(orc, objs).ppm(cam, W, H, 1, 5, nphotons=20000)
+    assert np.array_equal(small["image"], want["image"])
