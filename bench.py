@@ -96,7 +96,7 @@ def other_configs(dev_index):
 
     eye("C3 2048x2048 spp64 glass bunny + ChessBoard floor, thin lens", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 64)
     eye("C4 4096x4096 spp256 dragon (all rows on one GPU), thin lens", scenes.scene_dragon(), scenes.cam_dof(), 4096, 4096, 256)
-    tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    tex = scenes.stone_texture()
     objs = scenes.planes(tex) + [scenes.TriangleMesh.from_triangles(scenes.dragon_tris(), (0.25, 0.25, 0.5), 0.0, 0.0, 1)]
     sc = cg.Scene(objs, device=dev_index)
     sc.ppm_render(64, 48, 1, scenes.cam_pinhole(), 5, SEED, nphotons=1000)

@@ -34,12 +34,14 @@ class Grid(C.Structure):
 
 class Photons(C.Structure):
     _fields_ = [("light", C.c_double * 3), ("jitter", C.c_double), ("power", C.c_double), ("alpha", C.c_double),
-                ("nphotons", C.c_int64), ("hashsize", C.c_int32), ("batch", C.c_int32), ("seed", C.c_uint64)]
+                ("nphotons", C.c_int64), ("hashsize", C.c_int32), ("batch", C.c_int32), ("seed", C.c_uint64),
+                ("initial_radius", C.c_double), ("pair_cap", C.c_int64)]
 
 
 class PpmResult(C.Structure):
     _fields_ = [("image", C.c_void_p), ("rgb8", C.c_void_p), ("hp16", C.c_void_p), ("hp_cap", C.c_uint64),
-                ("hp_count", C.c_uint64), ("n_events", C.c_uint64), ("n_pairs", C.c_uint64), ("ms_eye", C.c_double),
+                ("hp_count", C.c_uint64), ("n_events", C.c_uint64), ("n_pairs", C.c_uint64), ("n_batch_halvings", C.c_uint64),
+                ("ms_eye", C.c_double),
                 ("ms_table", C.c_double), ("ms_photons", C.c_double), ("ms_gather", C.c_double)]
 
 
@@ -86,6 +88,8 @@ SIGNATURES = {
     "cgrt_scene_bvh_dump": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "cgrt_scene_bvh_order": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p]),
     "cgrt_lens_samples": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
+    "cgrt_surface_colors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "cgrt_trace_grid_variant": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_char_p, C.c_size_t]),
     "cgrt_intersect_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
 }

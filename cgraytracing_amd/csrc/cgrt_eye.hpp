@@ -364,4 +364,19 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     nrm[3 * i + 2] = h.n.z;
 }
 
+// function-level probe: objs[obj]->getSurfaceColor(P) (objects.h:84-86,533-539 -> Texture::color) for n points
+__global__ void surface_colors_kernel(DeviceScene sc, int obj, const double *__restrict__ pts, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ObjRec &ob = sc.objs[obj];
+    V3 f = ld3(ob.col);
+    if (ob.kind == KIND_PLANE && ob.tex >= 0) {
+        V3 c;
+        if (texture_color(sc.texs[ob.tex], sc.texels, ld3(pts + 3 * i), c)) f = c;
+    }
+    out[3 * i] = f.x;
+    out[3 * i + 1] = f.y;
+    out[3 * i + 2] = f.z;
+}
+
 #endif

@@ -65,6 +65,29 @@ static int fail(int code, const std::string &msg) {
             return fail(CGRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point that works on a scene's device switches to it for the duration of the call only: one host thread may
+// drive several GPUs (or run under a framework with its own current device) and must find its device unchanged afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define ON_DEVICE(dev)          \
+    DeviceGuard dev_guard_(dev); \
+    if (dev_guard_.err != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(dev_guard_.err))
+
 template <class T>
 static int upload(cgrt_scene *s, const std::vector<T> &v, const T **out) {
     *out = nullptr;
@@ -92,13 +115,11 @@ int cgrt_scene_create(cgrt_scene **out) {
 
 void cgrt_scene_destroy(cgrt_scene *s) {
     if (!s) return;
-    if (!s->allocs.empty()) {
-        int cur = 0;
-        if (hipGetDevice(&cur) == hipSuccess) {
-            (void)hipSetDevice(s->device);
+    if (!s->allocs.empty() || s->scratch) {
+        DeviceGuard g(s->device);
+        if (g.err == hipSuccess) {
             for (void *p : s->allocs) (void)hipFree(p);
             if (s->scratch) (void)hipFree(s->scratch);
-            (void)hipSetDevice(cur);
         }
     }
     delete s;
@@ -169,7 +190,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(CGRT_ERR_DEVICE, "no such HIP device");
-    HIP_TRY(hipSetDevice(device));
+    ON_DEVICE(device);
     s->device = device;
     HostScene &H = s->host;
     // flatten trees
@@ -225,17 +246,28 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         texs.push_back(tr);
     }
     DeviceScene d{};
-    int rc;
-    if ((rc = upload(s, H.objs, &d.objs))) return rc;
-    if ((rc = upload(s, nodes, &d.nodes))) return rc;
-    if ((rc = upload(s, tris, &d.tris))) return rc;
-    if ((rc = upload(s, trees, &d.trees))) return rc;
-    if ((rc = upload(s, texs, &d.texs))) return rc;
-    if ((rc = upload(s, texels, &d.texels))) return rc;
-    if ((rc = upload(s, H.beziers, &d.beziers))) return rc;
-    if ((rc = upload(s, hfields, &d.hfields))) return rc;
-    if ((rc = upload(s, hcells, &d.hcells))) return rc;
-    if ((rc = upload(s, otris, &d.otris))) return rc;
+    int rc = CGRT_OK;
+    // a commit that fails part-way leaves nothing behind: the scene stays open and a later commit starts from scratch
+    auto all_uploads = [&]() -> int {
+        if ((rc = upload(s, H.objs, &d.objs))) return rc;
+        if ((rc = upload(s, nodes, &d.nodes))) return rc;
+        if ((rc = upload(s, tris, &d.tris))) return rc;
+        if ((rc = upload(s, trees, &d.trees))) return rc;
+        if ((rc = upload(s, texs, &d.texs))) return rc;
+        if ((rc = upload(s, texels, &d.texels))) return rc;
+        if ((rc = upload(s, H.beziers, &d.beziers))) return rc;
+        if ((rc = upload(s, hfields, &d.hfields))) return rc;
+        if ((rc = upload(s, hcells, &d.hcells))) return rc;
+        if ((rc = upload(s, otris, &d.otris))) return rc;
+        return CGRT_OK;
+    };
+    if (all_uploads() != CGRT_OK) {
+        for (void *p : s->allocs) (void)hipFree(p);
+        s->allocs.clear();
+        s->device_bytes = 0;
+        s->device = -1;
+        return rc;
+    }
     d.n_objs = (int32_t)H.objs.size();
     d.n_trees = (int32_t)trees.size();
     d.n_texs = (int32_t)texs.size();
@@ -332,6 +364,23 @@ int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int3
     return CGRT_OK;
 }
 
+// Which instantiation of trace_grid_kernel a launch uses (chosen from the scene's materials and the camera).
+struct GridVariant {
+    bool trees, bez, dof, glass, sph, stats;
+    int nt;  // threads per workgroup: 256 (32x8-pixel tiles) or 64 (Bezier scenes: one-wave workgroups on 16x4 tiles)
+};
+static GridVariant grid_variant(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid) {
+    GridVariant v;
+    v.bez = s->dev.has_bezier != 0;
+    v.trees = s->dev.has_mesh != 0 || v.bez;  // Bezier scenes share the tree-capable variants
+    v.dof = cam->lens_radius > 0;
+    v.glass = s->dev.has_glass != 0 && grid->max_depth > 1;
+    v.sph = !v.trees && s->dev.all_spheres != 0;
+    v.stats = (grid->flags & CGRT_GRID_STATS) != 0 && s->dev.has_mesh != 0 && !v.bez;
+    v.nt = v.bez ? 64 : kThreads;
+    return v;
+}
+
 static int check_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *g) {
     if (!s || !cam || !g) return fail(CGRT_ERR_INVALID, "null argument");
     if (!s->committed) return fail(CGRT_ERR_INVALID, "scene not committed");
@@ -346,6 +395,16 @@ static int check_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_gr
         return fail(CGRT_ERR_INVALID, "bad row_offset");
     }
     if (!(cam->lens_radius >= 0)) return fail(CGRT_ERR_INVALID, "lens_radius must be >= 0");
+    return CGRT_OK;
+}
+
+int cgrt_trace_grid_variant(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, char *name, size_t cap) {
+    int rc = check_grid(s, cam, grid);
+    if (rc) return rc;
+    if (!name || cap == 0) return fail(CGRT_ERR_INVALID, "null name buffer");
+    const GridVariant v = grid_variant(s, cam, grid);
+    std::snprintf(name, cap, "trace_grid_kernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,HPS=0,NT=%d>", (int)v.trees,
+                  (int)v.bez, (int)v.dof, (int)v.glass, (int)v.sph, (int)v.stats, v.nt);
     return CGRT_OK;
 }
 
@@ -400,22 +459,17 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
     // launch on the scene's device whatever the caller's current device is (one host thread may drive several GPUs)
-    int caller_dev = s->device;
-    HIP_TRY(hipGetDevice(&caller_dev));
-    if (caller_dev != s->device) HIP_TRY(hipSetDevice(s->device));
-    const bool trees = s->dev.has_mesh != 0, dof = cam->lens_radius > 0, bez = s->dev.has_bezier != 0;
-    const bool glass = s->dev.has_glass != 0 && grid->max_depth > 1;
-    const bool stats = (grid->flags & CGRT_GRID_STATS) != 0 && trees && !bez;
+    ON_DEVICE(s->device);
+    const GridVariant gv = grid_variant(s, cam, grid);
+    const bool trees = s->dev.has_mesh != 0, dof = gv.dof, bez = gv.bez, glass = gv.glass, stats = gv.stats;
     if (g.chunks > 1) {
         const size_t need = (size_t)g.chunks * npx_all * (3 * sizeof(double) + sizeof(uint32_t));
         if (s->scratch_bytes < need) {
             if (s->scratch) (void)hipFree(s->scratch);
             s->scratch = nullptr;
             s->scratch_bytes = 0;
-            if (hipMalloc(&s->scratch, need) != hipSuccess) {
-                if (caller_dev != s->device) (void)hipSetDevice(caller_dev);
+            if (hipMalloc(&s->scratch, need) != hipSuccess)
                 return fail(CGRT_ERR_DEVICE, "split samples: cannot allocate the chunk sums");
-            }
             s->scratch_bytes = need;
         }
         g.partial = reinterpret_cast<double *>(s->scratch);
@@ -449,7 +503,6 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     if (g.chunks > 1)
         hipLaunchKernelGGL(finalize_chunks_kernel, dim3((unsigned)((npx_all + 255) / 256)), dim3(256), 0, st, g, rgb, nhit);
     const hipError_t launch_err = hipGetLastError();
-    if (caller_dev != s->device) (void)hipSetDevice(caller_dev);
     if (launch_err != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(launch_err));
     return CGRT_OK;
 }
@@ -521,7 +574,7 @@ int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const
     int rc = check_grid(s, cam, grid);
     if (rc) return rc;
     if (!count || (cap > 0 && !hp10)) return fail(CGRT_ERR_INVALID, "null output");
-    HIP_TRY(hipSetDevice(s->device));
+    ON_DEVICE(s->device);
     double *d_rec = nullptr;
     uint64_t n = 0;
     rc = hitpoints_device(s, cam, grid, cap, &d_rec, &n);
@@ -540,7 +593,7 @@ int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt
     int rc = check_grid(s, cam, grid);
     if (rc) return rc;
     if (!rgb) return fail(CGRT_ERR_INVALID, "null rgb");
-    HIP_TRY(hipSetDevice(s->device));
+    ON_DEVICE(s->device);
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_nhit, b_cnt;
     HIP_TRY(b_rgb.alloc(npx * 3 * sizeof(float)));
@@ -571,7 +624,7 @@ int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const 
     if (obj < 0 || obj >= s->dev.n_objs || n < 0 || !org3 || !dir3 || !hit || !len || !normal3)
         return fail(CGRT_ERR_INVALID, "bad argument");
     if (n == 0) return CGRT_OK;
-    HIP_TRY(hipSetDevice(s->device));
+    ON_DEVICE(s->device);
     DevBuf b_o, b_d, b_len, b_n, b_hit, b_keys;
     HIP_TRY(b_o.alloc((size_t)n * 24));
     HIP_TRY(b_d.alloc((size_t)n * 24));
@@ -595,6 +648,23 @@ int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const 
     HIP_TRY(hipMemcpy(hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(normal3, d_n, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return CGRT_OK;
+}
+
+int cgrt_surface_colors(const cgrt_scene *s, int obj, const double *points3, int n, double *colors3) {
+    if (!s || !s->committed) return fail(CGRT_ERR_INVALID, "scene not committed");
+    if (obj < 0 || obj >= s->dev.n_objs || n < 0 || (n > 0 && (!points3 || !colors3))) return fail(CGRT_ERR_INVALID, "bad argument");
+    if (n == 0) return CGRT_OK;
+    ON_DEVICE(s->device);
+    DevBuf b_p, b_c;
+    HIP_TRY(b_p.alloc((size_t)n * 24));
+    HIP_TRY(b_c.alloc((size_t)n * 24));
+    HIP_TRY(hipMemcpy(b_p.p, points3, (size_t)n * 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(surface_colors_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->dev, obj, b_p.as<double>(), n,
+                       b_c.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(colors3, b_c.p, (size_t)n * 24, hipMemcpyDeviceToHost));
     return CGRT_OK;
 }
 

@@ -229,8 +229,12 @@ __global__ void event_keys_kernel(const double *__restrict__ events, const unsig
 // the whole photon pass; counting first and writing in a second walk (the previous form) paid for every probe twice.
 constexpr int kPairBuf = 768;  // staged pairs per wave (6 KiB); flushed before an iteration that could overflow it
 
-__device__ __forceinline__ void pairs_flush(const unsigned long long *buf, unsigned cnt, unsigned base,
-                                            unsigned long long *__restrict__ keys, unsigned int *__restrict__ vals, unsigned cap) {
+// `base` is a position in the 64-bit count of ALL pairs the batch produces; only positions below `cap` exist in memory.  The
+// count itself is never clamped: the host compares the 64-bit total with cap and redoes an overflowing batch in halves (a
+// 32-bit count would wrap at settings within reach -- 5 M events x 1000 hitpoints inside the initial radius -- and pass).
+__device__ __forceinline__ void pairs_flush(const unsigned long long *buf, unsigned cnt, unsigned long long base,
+                                            unsigned long long *__restrict__ keys, unsigned int *__restrict__ vals,
+                                            unsigned long long cap) {
     const int lane = threadIdx.x & 63;
     for (unsigned k = lane; k < cnt; k += 64) {
         const unsigned long long key = buf[k];
@@ -246,10 +250,12 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
                                                            const unsigned int *__restrict__ order, int nslots, HashArgs ha,
                                                            const double *__restrict__ hp, const int *__restrict__ bstart,
                                                            unsigned long long *__restrict__ keys,
-                                                           unsigned int *__restrict__ vals, unsigned int *__restrict__ npairs,
-                                                           unsigned int cap) {
+                                                           unsigned int *__restrict__ vals,
+                                                           unsigned long long *__restrict__ npairs /* [0] pairs, [1] events */,
+                                                           unsigned long long cap) {
     __shared__ unsigned long long stage[4][kPairBuf];
-    __shared__ unsigned wave_cnt[4], wave_ev[4], block_base;
+    __shared__ unsigned wave_cnt[4], wave_ev[4];
+    __shared__ unsigned long long block_base;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool on = t < nslots && order_keys[t] != kNoEvent;
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
             }
             while (__ballot(i < i1) != 0ull) {  // all lanes step through their buckets together
                 if (cnt > (unsigned)(kPairBuf - 64)) {  // the next step could overflow: this wave reserves for itself
-                    unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(npairs, cnt);
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(npairs, (unsigned long long)cnt);
                     base = __shfl(base, 0);
                     pairs_flush(buf, cnt, base, keys, vals, cap);
                     cnt = 0;
@@ -304,11 +310,11 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
     if (threadIdx.x == 0) {
         const unsigned tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         const unsigned nev = wave_ev[0] + wave_ev[1] + wave_ev[2] + wave_ev[3];
-        block_base = tot ? atomicAdd(npairs, tot) : 0u;
-        if (nev) atomicAdd(npairs + 1, nev);  // events processed (statistics)
+        block_base = tot ? atomicAdd(npairs, (unsigned long long)tot) : 0ull;
+        if (nev) atomicAdd(npairs + 1, (unsigned long long)nev);  // events processed (statistics)
     }
     __syncthreads();
-    unsigned base = block_base;
+    unsigned long long base = block_base;
     for (int w = 0; w < wave; w++) base += wave_cnt[w];
     pairs_flush(buf, cnt, base, keys, vals, cap);
 }
@@ -415,7 +421,7 @@ extern "C" int cgrt_photon_events(const cgrt_scene *s, const cgrt_photons *ph, i
     if (!s || !s->committed || !ph || !events9 || !valid || count <= 0 || count > (1 << 20) || max_depth < 1 ||
         max_depth > kMaxDepth)
         return fail(CGRT_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(s->device));
+    ON_DEVICE(s->device);
     DevBuf ev, va;
     const size_t nslots = (size_t)count * kSegStride;
     HIP_TRY(ev.alloc(nslots * 9 * sizeof(double)));
@@ -463,7 +469,7 @@ struct Timer {  // device time between two points of the null stream
 
 extern "C" int cgrt_tonemap_rgb8(int device, const double *image, int width, int height, uint8_t *rgb8) {
     if (!image || !rgb8 || width < 1 || height < 1) return fail(CGRT_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(device));
+    ON_DEVICE(device);
     const size_t n = (size_t)width * height * 3;
     DevBuf img, out;
     HIP_TRY(img.alloc(n * sizeof(double)));
@@ -481,11 +487,12 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     int rc = check_grid(s, cam, grid);
     if (rc) return rc;
     if (!ph || !out) return fail(CGRT_ERR_INVALID, "null argument");
-    if (ph->nphotons < 0 || ph->hashsize < 1 || ph->hashsize > (1 << 20) || ph->batch < 0)
+    if (ph->nphotons < 0 || ph->hashsize < 1 || ph->hashsize > (1 << 20) || ph->batch < 0 || !(ph->initial_radius >= 0) ||
+        ph->pair_cap < 0)
         return fail(CGRT_ERR_INVALID, "bad photon parameters");
     if (grid->stripe_nranks > 1 && out->rgb8)
         return fail(CGRT_ERR_UNSUPPORTED, "photon pass: rgb8 needs contiguous rows; tone-map the assembled frame (cgrt_tonemap_rgb8)");
-    HIP_TRY(hipSetDevice(s->device));
+    ON_DEVICE(s->device);
     Timer tm;
     // ---- eye pass: hitpoint records, device resident (count first, then capture) ----
     tm.start();
@@ -511,7 +518,9 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     HIP_TRY(k0.alloc(n * 8)); HIP_TRY(k1.alloc(n * 8)); HIP_TRY(v0.alloc(n * 4)); HIP_TRY(v1.alloc(n * 4));
     HashArgs ha;
     ha.hashsize = ph->hashsize;
-    const double r0 = 200.0 / 768;  // main.cpp:84,183 with the reference's compile-time height
+    // main.cpp:84,183: r = 200.0 / height with the reference's COMPILE-TIME height (768) whatever frame is rendered;
+    // a host that mirrors a reference built for another height passes that build's 200/height here
+    const double r0 = ph->initial_radius > 0 ? ph->initial_radius : 200.0 / 768;
     ha.celllength = 70.0 / std::ceil(70.0 / r0);  // hash.h:25-26
     const int T = 256;
     const unsigned nb = (unsigned)((n + T - 1) / T);
@@ -535,16 +544,18 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     DevBuf ev, valid, pk0, pk1, pv0, pv1, npairs, ek0, ek1, eo0, eo1;
     // pairs per batch: room for 128 per hitpoint, between 4 M and 128 M (3 GiB of keys and values); a batch that overflows is halved
     const unsigned long long want_cap = (unsigned long long)n * 128ull;
-    const unsigned pair_cap = (unsigned)(want_cap < (1ull << 22) ? (1ull << 22) : (want_cap > (1ull << 27) ? (1ull << 27) : want_cap));
+    unsigned long long pair_cap = want_cap < (1ull << 22) ? (1ull << 22) : (want_cap > (1ull << 27) ? (1ull << 27) : want_cap);
+    if (ph->pair_cap > 0) pair_cap = (unsigned long long)ph->pair_cap < (1ull << 27) ? (unsigned long long)ph->pair_cap : (1ull << 27);
     HIP_TRY(ev.alloc((size_t)nslots_max * 9 * sizeof(double)));
     HIP_TRY(valid.alloc((size_t)nslots_max));
     HIP_TRY(pk0.alloc((size_t)pair_cap * 8)); HIP_TRY(pk1.alloc((size_t)pair_cap * 8));
     HIP_TRY(pv0.alloc((size_t)pair_cap * 4)); HIP_TRY(pv1.alloc((size_t)pair_cap * 4));
     HIP_TRY(ek0.alloc((size_t)nslots_max * 4)); HIP_TRY(ek1.alloc((size_t)nslots_max * 4));
     HIP_TRY(eo0.alloc((size_t)nslots_max * 4)); HIP_TRY(eo1.alloc((size_t)nslots_max * 4));
-    HIP_TRY(npairs.alloc(8));
+    HIP_TRY(npairs.alloc(16));
     out->n_events = 0;
     out->n_pairs = 0;
+    out->n_batch_halvings = 0;
     int pair_key_bits = 25;  // key = hitpoint << 24 | slot
     while (pair_key_bits < 64 && (n >> (pair_key_bits - 24)) != 0) pair_key_bits++;
     for (long long first = 0; first < ph->nphotons && n > 0;) {
@@ -557,7 +568,7 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
         pa.seed = ph->seed;
         const int nslots = pa.count * kSegStride;
         HIP_TRY(hipMemsetAsync(valid.p, 0, (size_t)nslots, 0));
-        HIP_TRY(hipMemsetAsync(npairs.p, 0, 8, 0));
+        HIP_TRY(hipMemsetAsync(npairs.p, 0, 16, 0));
         launch_photon_trace(s, pa, ev.as<double>(), valid.as<unsigned char>());
         hipLaunchKernelGGL(event_keys_kernel, dim3((nslots + T - 1) / T), dim3(T), 0, 0, ev.as<double>(), valid.as<unsigned char>(),
                            nslots, ha, ek0.as<unsigned int>(), eo0.as<unsigned int>());
@@ -565,16 +576,17 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
         if (rc) return rc;
         hipLaunchKernelGGL(photon_pairs_kernel, dim3((nslots + T - 1) / T), dim3(T), 0, 0, ev.as<double>(),
                            ek1.as<unsigned int>(), eo1.as<unsigned int>(), nslots, ha, hp.as<double>(), bstart.as<int>(),
-                           pk0.as<unsigned long long>(), pv0.as<unsigned int>(), npairs.as<unsigned int>(), pair_cap);
+                           pk0.as<unsigned long long>(), pv0.as<unsigned int>(), npairs.as<unsigned long long>(), pair_cap);
         HIP_TRY(hipGetLastError());
-        unsigned int np2[2] = {0, 0};  // pairs, events
-        HIP_TRY(hipMemcpy(np2, npairs.p, 8, hipMemcpyDeviceToHost));
-        const unsigned int np = np2[0];
-        if (np > pair_cap) {  // nothing has been applied yet: redo this range in smaller batches (same result)
-            if (batch <= 1024) return fail(CGRT_ERR_LIMIT, "photon pass: pair buffer overflow");
-            batch /= 2;
+        unsigned long long np2[2] = {0, 0};  // pairs (the full 64-bit count, stored or not), events
+        HIP_TRY(hipMemcpy(np2, npairs.p, 16, hipMemcpyDeviceToHost));
+        if (np2[0] > pair_cap) {  // nothing has been applied yet: redo this range in smaller batches (same result)
+            if (pa.count <= 1) return fail(CGRT_ERR_LIMIT, "photon pass: one photon's pairs exceed the pair buffer");
+            batch = (pa.count < batch ? pa.count : batch) / 2;
+            out->n_batch_halvings++;
             continue;
         }
+        const unsigned int np = (unsigned int)np2[0];  // <= pair_cap <= 2^27
         first += pa.count;
         out->n_events += np2[1];
         if (batch < batch_max && np < pair_cap / 4) batch *= 2;  // radii shrink as photons arrive: later batches hold fewer pairs

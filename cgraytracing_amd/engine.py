@@ -192,16 +192,19 @@ class Scene:
 
     def ppm_render(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, nphotons=100000, photon_seed=777,
                    hashsize=1000001, light=(0.0, 19.999, 20.0), jitter=2.0, power=700.0, alpha=0.7, batch=0,
-                   want_hitpoints=False, want_rgb8=False, rows=None, row_offset=0, stripe=None):
+                   want_hitpoints=False, want_rgb8=False, rows=None, row_offset=0, stripe=None, initial_radius=0.0,
+                   pair_cap=0):
         """Eye pass + photon pass + final gather (+ tone map): render() main.cpp:169-258 with the serial photon
         semantics, and the PNG pixel loop of main.cpp:403-412.
         rows / row_offset / stripe select this rank's share of the frame exactly as in trace_grid (every rank traces
         all photons and owns only its rows' hitpoints; the rows equal those of a full-frame call bit for bit).
+        initial_radius: the reference's 200/height of main.cpp:84,183 (0 = 200/768, its committed height); pair_cap: size
+        of the per-batch pair buffer (0 = automatic; the result does not depend on it).
         Returns dict(image [rows,W,3] float64 (row 0 = bottom), count, n_events, n_pairs, ms (stage times); with
         want_hitpoints: hp [n,16]; with want_rgb8 (contiguous rows only): rgb8 [rows,W,3] uint8, top row first)."""
         rows = height if rows is None else rows
         cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, 0, None, 0)
-        ph = _capi.Photons(_d3(light), jitter, power, alpha, nphotons, hashsize, batch, photon_seed)
+        ph = _capi.Photons(_d3(light), jitter, power, alpha, nphotons, hashsize, batch, photon_seed, initial_radius, pair_cap)
         height = rows
         img = np.zeros((height, width, 3), np.float64)
         cap = height * width * spp * 16 if want_hitpoints else 0
@@ -211,6 +214,7 @@ class Scene:
                               hp.ctypes.data if want_hitpoints else None, cap)
         check(self._L.cgrt_ppm_render(self._h, C.byref(cc), C.byref(g), C.byref(ph), C.byref(res)))
         out = dict(image=img, count=int(res.hp_count), n_events=int(res.n_events), n_pairs=int(res.n_pairs),
+                   n_batch_halvings=int(res.n_batch_halvings),
                    ms=dict(eye=res.ms_eye, table=res.ms_table, photons=res.ms_photons, gather=res.ms_gather))
         if want_hitpoints:
             out["hp"] = hp[: int(res.hp_count)]
@@ -222,12 +226,27 @@ class Scene:
                       power=700.0):
         """Verification probe: diffuse hits of photons [first, first+count): [n,10] = photon, P, n, flux in serial
         order (slot order)."""
-        ph = _capi.Photons(_d3(light), jitter, power, 0.7, count, 1000001, 0, photon_seed)
+        ph = _capi.Photons(_d3(light), jitter, power, 0.7, count, 1000001, 0, photon_seed, 0.0, 0)
         ev = np.zeros((count * 8, 9), np.float64)
         va = np.zeros(count * 8, np.uint8)
         check(self._L.cgrt_photon_events(self._h, C.byref(ph), max_depth, first, count, ev.ctypes.data, va.ctypes.data))
         idx = np.nonzero(va)[0]
         return np.concatenate([(first + idx // 8)[:, None].astype(np.float64), ev[idx]], axis=1)
+
+    def surface_colors(self, obj, pts):
+        """objs[obj]->getSurfaceColor(P) on the device for each row of pts [n,3] (function-level probe)."""
+        pts = np.ascontiguousarray(pts, np.float64)
+        out = np.zeros_like(pts)
+        check(self._L.cgrt_surface_colors(self._h, self.obj_index[obj], pts.ctypes.data, len(pts), out.ctypes.data))
+        return out
+
+    def kernel_variant(self, width, height, spp=1, camera=None, max_depth=5, rows=None, stripe=None, flags=0):
+        """Name of the trace_grid_kernel instantiation this grid launches (what a rocprofv3 kernel trace shows)."""
+        rows = height if rows is None else rows
+        cc, g = self._structs(camera, width, height, rows, spp, max_depth, 0, 0, stripe, 0, None, flags)
+        buf = C.create_string_buffer(160)
+        check(self._L.cgrt_trace_grid_variant(self._h, C.byref(cc), C.byref(g), buf, len(buf)))
+        return buf.value.decode()
 
     def intersect_rays(self, obj, org, dirs, keys=None):
         org = np.ascontiguousarray(org, np.float64)

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define CGRT_VERSION 100 /* 0.1.0 */
+#define CGRT_VERSION 110 /* 0.1.1: cgrt_photons.initial_radius / .pair_cap, cgrt_ppm_result.n_batch_halvings,
+                            cgrt_surface_colors, cgrt_trace_grid_variant */
 
 enum {
     CGRT_OK = 0,
@@ -198,6 +199,13 @@ typedef struct cgrt_photons {
     int32_t hashsize;  /* main.cpp:184: 1000001 (bucket collisions are part of the semantics, hash.h:32-37)         */
     int32_t batch;     /* photons traced per batch (0 = default 1048576); does not change the result               */
     uint64_t seed;
+    double initial_radius; /* radius every Hitpoint starts with and, through it, the hash cell length (hash.h:25-26).
+                            * The reference ties both to its compile-time `height`: r = 200.0/height (main.cpp:84,183),
+                            * 200/768 as committed.  0 selects 200/768; a host mirroring a reference built for another
+                            * height passes that build's 200.0/height                                               */
+    int64_t pair_cap;  /* capacity of the per-batch (hitpoint, photon hit) pair buffer; 0 = automatic (128 per hitpoint,
+                        * between 4 M and 128 M).  A batch whose pairs do not fit is redone in halves -- the result does
+                        * not depend on it; tests set it low to drive that path                                     */
 } cgrt_photons;
 
 /* What cgrt_ppm_render hands back; every pointer is a HOST buffer owned by the caller and may be NULL. */
@@ -212,6 +220,7 @@ typedef struct cgrt_ppm_result {
     uint64_t hp_count; /* out: hitpoints the eye pass produced                                                     */
     uint64_t n_events; /* out: diffuse photon hits processed (main.cpp:103-125 executions)                         */
     uint64_t n_pairs;  /* out: (hitpoint, photon hit) candidate pairs replayed                                      */
+    uint64_t n_batch_halvings; /* out: times a batch overflowed the pair buffer and was redone in halves            */
     double ms_eye, ms_table, ms_photons, ms_gather; /* out: device time of the four stages, milliseconds            */
 } cgrt_ppm_result;
 
@@ -244,6 +253,15 @@ int cgrt_photon_events(const cgrt_scene *s, const cgrt_photons *ph, int max_dept
  * device (host pointers; keys: per-ray stream key for Bezier draws, may be NULL). */
 int cgrt_intersect_rays(const cgrt_scene *s, int obj, const double *org3, const double *dir3, const uint64_t *keys,
                         int n, int32_t *hit, double *len, double *normal3);
+
+/* Function-level probe: objs[obj]->getSurfaceColor(P) for n points on the device -- the flat colour, or for a textured
+ * plane Texture::color (texture.h:39-72: three axis-aligned orientations, nearest texel) with the flat colour outside
+ * the texture rectangle (objects.h:533-539).  HOST buffers, n*3 doubles each. */
+int cgrt_surface_colors(const cgrt_scene *s, int obj, const double *points3, int n, double *colors3);
+
+/* Name of the trace_grid_kernel instantiation cgrt_trace_grid would launch for (scene, cam, grid) -- the kernel name a
+ * rocprofv3 kernel trace shows; written NUL-terminated into name[cap]. */
+int cgrt_trace_grid_variant(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, char *name, size_t cap);
 
 /* Host evaluation of the lens stream (cgrt_rng.hpp, the same inline code the kernel runs): writes
  * uniform_sampling_circle(radius) (sampling.h:35-43) for n (pixel, sample) pairs as 3 doubles each.  Lets CPU-only

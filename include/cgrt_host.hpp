@@ -335,6 +335,8 @@ struct PhotonParams {
     int num_threads = 8;                   // main.cpp:224: total photons = num_photon * num_threads
     int hashsize = 1000001;                // main.cpp:184
     uint64_t seed = 777;
+    double initial_radius = 0.0;           // main.cpp:84,183: 200.0 / height with the reference's compile-time height;
+                                           // 0 = the committed 200.0 / 768
 };
 struct PpmStats {
     uint64_t hitpoints = 0, photon_events = 0;
@@ -372,6 +374,7 @@ inline void render_ppm(const std::vector<Object *> &objs, const RenderParams &rp
     ph.nphotons = pp.num_photon * pp.num_threads;
     ph.hashsize = pp.hashsize;
     ph.seed = pp.seed;
+    ph.initial_radius = pp.initial_radius;  // 0: the reference's committed 200.0 / 768 (main.cpp:84,183)
     image.assign((size_t)rp.width * rp.height * 3, 0.0);
     image_data.assign((size_t)rp.width * rp.height * 3, 0);
     cgrt_ppm_result out{};

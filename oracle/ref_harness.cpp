@@ -418,4 +418,19 @@ void ref_tonemap(const double *image, int W, int H, uint8_t *out) {
         }
 }
 
+// ---- texture decoding with the reference's own vendored decoder (stbi_load(..., 3), main.cpp:300): used once, by
+// tests/golden/make_assets.py, to turn texture/stone.jpg into the byte asset the reference's main() would see.
+// out may be NULL (size query).  Returns 0 on success.
+int ref_decode_image(const char *path, int *w, int *h, uint8_t *out, uint64_t cap) {
+    int ww = 0, hh = 0, bpp = 0;
+    unsigned char *px = stbi_load(path, &ww, &hh, &bpp, 3);
+    if (!px) return -1;
+    if (w) *w = ww;
+    if (h) *h = hh;
+    const uint64_t need = (uint64_t)ww * hh * 3;
+    if (out && cap >= need) memcpy(out, px, need);
+    stbi_image_free(px);
+    return 0;
+}
+
 }  // extern "C"

@@ -5,6 +5,9 @@ Runs only where /root/reference exists; outputs are committed.  Data only -- no 
                       a=10, b=(0,-15,40) (main.cpp:293): [966, 9] float64
   chessboard_rgb.npz  texture/ChessBoard.png decoded to RGB (alpha dropped, as stbi_load(...,3) does)
   stone_small_rgb.npz texture/stone.jpg decoded by PIL and box-resized to 150x100 (bump-map fixture)
+  stone_rgb.npz       texture/stone.jpg at its full 1000x667, decoded by the REFERENCE's own vendored decoder
+                      (stbi_load(..., 3), main.cpp:300, through oracle/_ref's ref_decode_image) -- the bytes main()
+                      sees; PIL's decode differs from it by +-1 in 0.8 % of the bytes, so PIL is not used here
   dragon_mesh.npz     model/dragon.txt as int32 vertices (x 1e4, exact: the file has 4 decimals) + faces
 """
 import os
@@ -39,6 +42,18 @@ def main():
         np.savez_compressed(os.path.join(OUT, "chessboard_rgb.npz"), rgb=rgb)
         st = Image.open(os.path.join(REF, "texture/stone.jpg")).convert("RGB").resize((150, 100), Image.BOX)
         np.savez_compressed(os.path.join(OUT, "stone_small_rgb.npz"), rgb=np.ascontiguousarray(np.asarray(st)))
+    if which in ("all", "stone"):
+        import ctypes as C
+        from backends import REF_SO
+        L = C.CDLL(REF_SO)
+        L.ref_decode_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_uint64]
+        path = os.path.join(REF, "texture/stone.jpg").encode()
+        w, h = C.c_int(), C.c_int()
+        assert L.ref_decode_image(path, C.byref(w), C.byref(h), None, 0) == 0
+        assert (w.value, h.value) == (1000, 667)
+        buf = np.zeros((h.value, w.value, 3), np.uint8)
+        assert L.ref_decode_image(path, C.byref(w), C.byref(h), buf.ctypes.data, buf.size) == 0
+        np.savez_compressed(os.path.join(OUT, "stone_rgb.npz"), rgb=buf)
     if which in ("all", "dragon"):
         verts, faces = [], []
         with open(os.path.join(REF, "model/dragon.txt")) as f:

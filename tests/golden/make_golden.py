@@ -43,6 +43,13 @@ def trace_cases():
         ("dragon_64", S.scene_dragon, S.cam_pinhole, 64, 64, 1, 5),
         ("stone_bump_64x48", bump_scene, S.cam_pinhole, 64, 48, 1, 5),
         ("chess_bump_48x36", chess_bump, S.cam_pinhole, 48, 36, 1, 5),
+        # round 2: Texture::color in all three orientations under mirror / glass reflections; the reference's real floor
+        # texture at full size (texture/stone.jpg, 146 744 bump triangles); a refracting bump floor (tree path)
+        ("textured_walls_64x48", S.scene_textured_walls, S.cam_pinhole, 64, 48, 1, 5),
+        ("textured_walls_dof_48x36", S.scene_textured_walls, S.cam_dof, 48, 36, 2, 5),
+        ("stone_full_bump_64x48", lambda: S.planes(S.stone_texture(True)) + [S.Sphere((5, -12, 30), 5, (1, 1, 1), 0.8, 0.5)],
+         S.cam_pinhole, 64, 48, 1, 5),
+        ("glass_bump_floor_48x36", S.scene_glass_bump_floor, S.cam_pinhole, 48, 36, 1, 5),
     ]
 
 
@@ -147,8 +154,14 @@ def main():
         return loader_child(sys.argv[2])
     ref = Backend("ref")
     meta = {}
+    # `only NAME...`: (re)generate just these trace fixtures and merge their entries into trace_meta.json
+    only = set(sys.argv[2:]) if len(sys.argv) > 2 and sys.argv[1] == "only" else None
+    if only:
+        meta = json.load(open(os.path.join(HERE, "trace_meta.json")))
     # ---- trace-level fixtures ----
     for name, mk, cam, W, H, spp, depth in trace_cases():
+        if only and name not in only:
+            continue
         s = BackendScene(ref, mk())
         r = s.trace_grid(cam(), W, H, spp, depth, seed=12345, capture=True)
         assert r["nhp"] == len(r["hp"])
@@ -165,6 +178,9 @@ def main():
                 meta[name]["bump_tree"] = fingerprint(nodes, leaf)
                 meta[name]["bump_tris_sha256"] = hashlib.sha256(s.bump_tris(p).tobytes()).hexdigest()
         print(name, meta[name])
+    if only:
+        json.dump(meta, open(os.path.join(HERE, "trace_meta.json"), "w"), indent=1, sort_keys=True)
+        return
     # ---- lens sampler (the reference's uniform_sampling_circle on the keyed stream) ----
     rng = np.random.default_rng(5)
     pix = rng.integers(0, 1920 * 1080, 512)

@@ -57,7 +57,7 @@ def cpu_run(objs, cam, W, H, spp, depth, row0, nrows, gpu_rows=None):
 def main():
     quick = "--quick" in sys.argv
     dof, pin = scenes.cam_dof(), scenes.cam_pinhole()
-    tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    tex = scenes.stone_texture()
     cfgs = [
         # name, objs, camera, W, H, spp (measured), spp (config), depth, rows rendered, crop rows for CPU (start, n, spp)
         ("C1 256x256 spp1 spheres depth1", scenes.scene_c1(), pin, 256, 256, 1, 1, 1, None, (0, 256, 1)),

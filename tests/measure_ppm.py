@@ -34,7 +34,7 @@ def main():
     args = ap.parse_args()
     W, H = args.width, args.height
     if args.scene == "committed":
-        tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+        tex = scenes.stone_texture()
         objs = scenes.planes(tex) + [scenes.TriangleMesh.from_triangles(scenes.dragon_tris(), (0.25, 0.25, 0.5), 0.0, 0.0, 1)]
     elif args.scene == "c2":
         objs = scenes.scene_c2()

@@ -5,8 +5,8 @@
 typedef char check_camera_size[(sizeof(cgrt_camera) == 48) ? 1 : -1];
 typedef char check_grid_size[(sizeof(cgrt_grid) == 56) ? 1 : -1];
 typedef char check_stats_size[(sizeof(cgrt_scene_stats) == 64) ? 1 : -1];
-typedef char check_photons_size[(sizeof(cgrt_photons) == 72) ? 1 : -1];
-typedef char check_ppm_result_size[(sizeof(cgrt_ppm_result) == 88) ? 1 : -1];
+typedef char check_photons_size[(sizeof(cgrt_photons) == 88) ? 1 : -1];
+typedef char check_ppm_result_size[(sizeof(cgrt_ppm_result) == 96) ? 1 : -1];
 
 int cgrt_abi_smoke(void) {
     cgrt_scene *s = 0;
@@ -20,8 +20,8 @@ int cgrt_abi_smoke(void) {
     if (cgrt_scene_create(&s) != CGRT_OK) return 2;
     if (cgrt_scene_add_sphere(s, c, 5.0, col, 0.0, 0.0) != 0) return 3;
     {
-        cgrt_photons ph = {{0.0, 19.999, 20.0}, 2.0, 700.0, 0.7, 1000, 1000001, 0, 777};
-        cgrt_ppm_result out = {0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};
+        cgrt_photons ph = {{0.0, 19.999, 20.0}, 2.0, 700.0, 0.7, 1000, 1000001, 0, 777, 0.0, 0};
+        cgrt_ppm_result out = {0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};
         if (cgrt_ppm_render(s, &cam, &g, &ph, &out) != CGRT_ERR_INVALID) return 5; /* uncommitted scene */
         if (cgrt_tonemap_rgb8(0, 0, 4, 4, 0) != CGRT_ERR_INVALID) return 6;          /* null buffers */
         if (cgrt_write_png(0, 4, 4, 0) != CGRT_ERR_INVALID) return 7;

@@ -68,13 +68,13 @@ if __name__ == "__main__":
         run("c4 dragon 512 spp64", scenes.scene_dragon(), scenes.cam_dof(), 512, 512, 64, 5, reps=2)
         run("c4 dragon 2048 spp16", scenes.scene_dragon(), scenes.cam_dof(), 2048, 2048, 16, 5, reps=1)
     if "c5" in which:
-        tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+        tex = scenes.stone_texture()
         run("c5 bump only", scenes.planes(tex), scenes.cam_dof(), 1024, 1024, 2, 5, reps=1, stats=True)
         run("c5 bump+vase", scenes.scene_c5(tex), scenes.cam_dof(), 1536, 1536, 2, 5, reps=1)
         run("vase only", scenes.planes() + [scenes.vase_bezier()], scenes.cam_dof(), 1536, 1536, 2, 5, reps=1)
     if "c5band" in which:  # a slice of C5 at its real width: 256 rows through the vase, stone-sized bump floor
-        tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+        tex = scenes.stone_texture()
         run("c5 band rows 3000..3255", scenes.scene_c5(tex), scenes.cam_dof(), 8192, 8192, 16, 5, reps=1, rows=256, row_offset=3000)
     if "c5full" in which:  # BASELINE.json configs[4], one GPU's share at the full sample count: 8192 x 1024 rows, spp 1024
-        tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+        tex = scenes.stone_texture()
         run("c5 share, spp 1024", scenes.scene_c5(tex), scenes.cam_dof(), 8192, 8192, 1024, 5, reps=1, rows=1024, row_offset=3584)

@@ -62,8 +62,15 @@ def stone_small_texture(bump=True):
     return Texture(d, (0, 1, 0), (-21, 0, 0), 42, 40, bump)
 
 
+def stone_texture(bump=True):
+    """texture/stone.jpg at its full 1000x667 as the reference's stb decoder returns it, placed as main.cpp:320 does:
+    Texture(tdata, (0,1,0), (-21,0,0), 42, 40, true).  As a bump map: 146 744 triangles, 32 767 nodes."""
+    d = load_asset("stone_rgb.npz")["rgb"]
+    return Texture(d, (0, 1, 0), (-21, 0, 0), 42, 40, bump)
+
+
 def procedural_stone(rows=667, cols=1000, seed=7):
-    """Seeded stand-in for texture/stone.jpg at its size (the JPEG itself is not shipped)."""
+    """Seeded stand-in of texture/stone.jpg's size (kept for fuzz-style tests; the configurations use stone_texture())."""
     rng = np.random.default_rng(seed)
     base = rng.random((rows // 8 + 2, cols // 8 + 2))
     up = np.kron(base, np.ones((8, 8)))[:rows, :cols]
@@ -141,6 +148,40 @@ def vase_bezier(refl=0.5, transp=0.0):
 def scene_c5(tex=None):
     """C5: planes with bump floor + Bezier vase."""
     return planes(tex) + [vase_bezier()]
+
+
+def textured_walls():
+    """Textures in all three orientations of Texture::color (texture.h:39-72): the chessboard on the floor (|d.y| branch),
+    on the back wall (|d.z| branch, vertically flipped) and on the right-hand wall (|d.x| branch, tested first), sized so
+    that part of every wall lies outside the texture rectangle (flat colour there, objects.h:533-539)."""
+    chess = load_asset("chessboard_rgb.npz")["rgb"]
+    floor = Texture(chess, (0, 1, 0), (-21, -20, 0), 42, 40, False)
+    back = Texture(chess, (0, 0, -1), (-15, -18, 40), 30, 25, False)
+    side = Texture(chess, (-1, 0, 0), (20, -16, 5), 30, 28, False)
+    return [
+        Plane((0.0, -20, 0), (0, 1, 0), (0.15, 0.15, 0.15), 0.0, 0.0, floor),
+        Plane((20, 0.0, 0), (-1, 0, 0), (0.15, 0.50, 0.15), 0.0, 0.0, side),
+        Plane((-20, 0.0, 0), (1, 0, 0), (0.50, 0.15, 0.15), 0.0, 0.0),
+        Plane((0.0, 0.0, 40), (0, 0, -1), (0.15, 0.15, 0.15), 0.0, 0.0, back),
+        Plane((0.0, 20, 0), (0, -1, 0), (0.15, 0.15, 0.15), 0.0, 0.0),
+    ]
+
+
+def scene_textured_walls():
+    """textured_walls() + a mirror and a glass sphere, so reflected and refracted rays reach the walls at all angles."""
+    return textured_walls() + [Sphere((9.0, -13.0, 30), 7, (1.0, 1.0, 1.0), 0.8, 0.0),
+                               Sphere((-8.0, -13.0, 25), 7, (1.0, 1.0, 1.0), 0.8, 0.5)]
+
+
+def scene_glass_bump_floor():
+    """A TRANSPARENT bump-mapped floor: its displacement mesh goes through the tree (the improvement counter is observable
+    for a refracting owner), not the height-field walk of opaque floors; a second textured floor below catches
+    the refracted rays."""
+    pl = planes(None)
+    pl[0] = Plane((0.0, -20, 0), (0, 1, 0), (0.9, 0.9, 0.9), 0.8, 0.5, chessboard_texture(True))
+    chess = load_asset("chessboard_rgb.npz")["rgb"]
+    below = Plane((0.0, -24, 0), (0, 1, 0), (0.2, 0.2, 0.3), 0.0, 0.0, Texture(chess, (0, 1, 0), (-30, -24, 0), 60, 60, False))
+    return pl + [below]
 
 
 def cam_pinhole():

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libcgrt.so does not export %s" % name
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
-    assert _capi.lib().cgrt_version() == 100
+    assert _capi.lib().cgrt_version() == 110
 
 
 def test_struct_layouts_match_header():
@@ -38,8 +38,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Camera) == 48
     assert C.sizeof(_capi.Grid) == 56  # 12 x int32 + uint64
     assert C.sizeof(_capi.SceneStats) == 8 * 4 + 4 * 8
-    assert C.sizeof(_capi.Photons) == 72       # 6 doubles, int64, 2 x int32, uint64 (pinned in tests/native/abi_c99.c too)
-    assert C.sizeof(_capi.PpmResult) == 88     # 3 pointers, 4 x uint64, 4 doubles
+    assert C.sizeof(_capi.Photons) == 88       # 6 doubles, int64, 2 x int32, uint64, double, int64 (pinned in tests/native/abi_c99.c too)
+    assert C.sizeof(_capi.PpmResult) == 96     # 3 pointers, 5 x uint64, 4 doubles
 
 
 def test_error_reporting_without_gpu_or_bad_args():
@@ -91,7 +91,8 @@ def test_product_loaders_and_tree_build_match_reference(name):
 
 
 @pytest.mark.parametrize("case,key", [("bunny_glass_chess_64", "mesh_tree"), ("dragon_64", "mesh_tree"),
-                                      ("stone_bump_64x48", "bump_tree"), ("chess_bump_48x36", "bump_tree")])
+                                      ("stone_bump_64x48", "bump_tree"), ("chess_bump_48x36", "bump_tree"),
+                                      ("stone_full_bump_64x48", "bump_tree"), ("glass_bump_floor_48x36", "bump_tree")])
 def test_product_tree_fingerprints(case, key):
     import cgraytracing_amd as cg
     mk = {c[0]: c[1] for c in make_golden.trace_cases()}[case]

@@ -99,7 +99,7 @@ def test_c5_shape_bump_and_bezier(gpu_ready, orc):
     """configs[4] shape: 8192-wide rows, stone-sized bump floor (146 744 triangles) + Bezier vase, one GPU's
     share reduced to 8192 x 64 rows and spp 4."""
     import cgraytracing_amd as cg
-    tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    tex = scenes.stone_texture()
     objs = scenes.scene_c5(tex)
     W, H, spp = 8192, 8192, 4
     cam = scenes.cam_dof()
@@ -165,7 +165,7 @@ def test_reference_main_configuration_properties(gpu_ready, orc):
     on its own equals the same rows of the full frame bit for bit, the tone-mapped bytes are the reference gammaCorr of
     the gathered image, and the first 20 000 photons alone give the oracle's serial image bit for bit."""
     import cgraytracing_amd as cg
-    tex = scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)
+    tex = scenes.stone_texture()
     objs = scenes.planes(tex) + [scenes.TriangleMesh.from_triangles(scenes.dragon_tris(), (0.25, 0.25, 0.5), 0.0, 0.0, 1)]
     W, H, nph = 1024, 768, 2000000
     cam = scenes.cam_pinhole()

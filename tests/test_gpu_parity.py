@@ -28,6 +28,14 @@ CASES = [
      lambda: scenes.planes(scenes.stone_small_texture(True)) + [scenes.Sphere((5, -12, 30), 5, (1, 1, 1), 0.8, 0.5)],
      scenes.cam_dof, 96, 72, 2, 5),
     ("ragged_size", scenes.scene_c2, scenes.cam_dof, 67, 45, 3, 5),
+    # Texture::color in all three orientations (texture.h:39-72) reached by primary, mirrored and refracted rays
+    ("textured_walls", scenes.scene_textured_walls, scenes.cam_dof, 160, 120, 4, 5),
+    # a refracting bump floor: displacement mesh through the tree path (counter observable), not the height field
+    ("glass_bump_floor", scenes.scene_glass_bump_floor, scenes.cam_dof, 96, 72, 2, 5),
+    # the reference's real floor texture at full size (texture/stone.jpg: 146 744 bump triangles)
+    ("stone_full_bump_floor",
+     lambda: scenes.planes(scenes.stone_texture(True)) + [scenes.Sphere((5, -12, 30), 5, (1, 1, 1), 0.8, 0.5)],
+     scenes.cam_dof, 128, 96, 2, 5),
 ]
 
 
@@ -78,6 +86,76 @@ def test_function_level_intersect_vs_reference_golden(gpu_ready):
         assert np.array_equal(h, g[k + "_hit"]), k
         assert np.array_equal(l[m], g[k + "_len"][m]) and np.array_equal(n[m], g[k + "_n"][m]), k
     s4.close()
+
+
+def test_texture_color_three_orientations_vs_reference_golden(gpu_ready):
+    """Texture::color on the DEVICE (cgrt_surface_colors -> texture_color) in all three orientations against the compiled
+    reference's own getSurfaceColor answers (function_level.npz: back_col = |d.z| branch with the vertical flip,
+    side_col = |d.x| branch, floor_col = |d.y| branch), points inside and outside the texture rectangle: bit for bit."""
+    import cgraytracing_amd as cg
+    from cgraytracing_amd.scene import Plane, Texture
+    g = np.load(__import__("os").path.join(GOLD, "function_level.npz"))
+    chess = scenes.load_asset("chessboard_rgb.npz")["rgb"]
+    back = Plane((0, 0, 40), (0, 0, -1), (0.15, 0.15, 0.15), 0, 0, Texture(chess, (0, 0, -1), (-10, -10, 40), 20, 10))
+    side = Plane((20, 0, 0), (-1, 0, 0), (0.15, 0.5, 0.15), 0, 0, Texture(chess, (-1, 0, 0), (20, -10, 10), 20, 25))
+    with cg.Scene([back, side]) as sc:
+        cb = sc.surface_colors(0, g["back_pts"])
+        cs = sc.surface_colors(1, g["side_pts"])
+    assert np.array_equal(cb, g["back_col"]) and np.array_equal(cs, g["side_col"])
+    for c, flat in ((g["back_col"], (0.15, 0.15, 0.15)), (g["side_col"], (0.15, 0.5, 0.15))):
+        inside = ~np.all(c == np.asarray(flat), axis=1)
+        assert 0.1 < inside.mean() < 0.9  # both the textured and the flat-colour outcome are exercised
+    with cg.Scene(scenes.scene_c3(True)) as s3:
+        P = g["mesh_org"] + g["mesh_dir"] * g["floor_len"][:, None]
+        assert np.array_equal(s3.surface_colors(0, P), g["floor_col"])
+
+
+def test_tangent_rays_on_opaque_mesh(gpu_ready, orc):
+    """The documented exception of the pruned traversal (cgrt_traverse.hpp, PRUNE): for an OPAQUE mesh the device
+    drops the improvement counter, which only sets the SIGN of the returned normal; trace() re-orients the normal
+    whenever n.d != 0 (main.cpp:73-76).  Rays lying exactly in a triangle's plane have det1 == 0 and miss it in the
+    reference (inf/NaN comparisons, objects.h:101-104) and here; rays a few ulps off the plane hit with |n.d| ~ 1e-16
+    and must give the same hit, distance and -- after trace()'s re-orientation -- the same Hitpoint normals."""
+    import cgraytracing_amd as cg
+    tris = scenes.pyramid_tris(1.0, (0.0, -5.0, 30.0))
+    mesh = scenes.TriangleMesh.from_triangles(tris, (0.6, 0.7, 0.9), 0.0, 0.0)
+    objs = [mesh]
+    rng = np.random.default_rng(5)
+    org, dirs = [], []
+    for t in tris.reshape(-1, 3, 3):
+        a, b, c = t
+        nrm = np.cross(a - b, a - c)
+        nrm /= np.linalg.norm(nrm)
+        for _ in range(400):
+            w = rng.dirichlet((1, 1, 1))
+            target = w[0] * a + w[1] * b + w[2] * c              # a point of the triangle
+            u = rng.normal(size=3)
+            u -= nrm * (u @ nrm)                                   # direction inside the triangle's plane ...
+            u /= np.linalg.norm(u)
+            tilt = rng.choice([0.0, 0.0, 1e-17, -1e-17, 1e-15, -1e-15, 1e-12, -1e-12, 1e-9, -1e-9])
+            d = u + nrm * tilt                                     # ... or tilted out of it by a few ulps
+            d /= np.linalg.norm(d)
+            org.append(target - d * rng.uniform(3, 30))
+            dirs.append(d)
+    org, dirs = np.asarray(org), np.asarray(dirs)
+    hw, lw, nw = BackendScene(orc, objs).intersect_batch(0, org, dirs)
+    with cg.Scene(objs) as sc:
+        hg, lg, ng = sc.intersect_rays(0, org, dirs)
+    assert np.array_equal(hg, hw) and 0.2 < hw.mean() < 0.99
+    m = hw != 0
+    assert np.array_equal(lg[m], lw[m])
+    same = np.all(ng[m] == nw[m], axis=1) | np.all(ng[m] == -nw[m], axis=1)
+    assert same.all()
+    nd = np.einsum("ij,ij->i", nw[m], dirs[m])
+    # what trace() does next (main.cpp:73-76): flip when n.d > 0.  Equal after the flip unless n.d == 0 exactly.
+    fo = np.where((nd > 0)[:, None], -nw[m], nw[m])
+    ndg = np.einsum("ij,ij->i", ng[m], dirs[m])
+    fg = np.where((ndg > 0)[:, None], -ng[m], ng[m])
+    exact_tangent = nd == 0
+    assert np.array_equal(fo[~exact_tangent], fg[~exact_tangent])
+    print("near-tangent hits: %d, min |n.d| = %.3e, exactly tangent hits: %d" % (m.sum(), np.abs(nd[~exact_tangent]).min(),
+                                                                               int(exact_tangent.sum())))
+    assert np.abs(nd).min() < 1e-12  # the fan really reaches the grazing regime
 
 
 def test_bezier_intersect_vs_reference_golden(gpu_ready):
@@ -287,7 +365,7 @@ def _bump_floor_rays(tex, n, seed):
     return o, d
 
 
-@pytest.mark.parametrize("which", ["stone_small", "chessboard", "procedural_stone"])
+@pytest.mark.parametrize("which", ["stone_small", "chessboard", "procedural_stone", "stone"])
 def test_bump_floor_grid_walk_vs_oracle(gpu_ready, orc, which):
     """Plane::intersect with a bump map (objects.h:505-524) for an opaque floor runs the height-field walk on the
     device while the oracle runs the reference's tree: hit flag and distance must be identical
@@ -295,9 +373,10 @@ def test_bump_floor_grid_walk_vs_oracle(gpu_ready, orc, which):
     overrides, main.cpp:73-76), including rays through shared edges and vertices."""
     import cgraytracing_amd as cg
     tex = {"stone_small": lambda: scenes.stone_small_texture(True), "chessboard": lambda: scenes.chessboard_texture(True),
-           "procedural_stone": lambda: scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True)}[which]()
+           "procedural_stone": lambda: scenes.Texture(scenes.procedural_stone(), (0, 1, 0), (-21, 0, 0), 42, 40, True),
+           "stone": lambda: scenes.stone_texture(True)}[which]()
     objs = scenes.planes(tex)
-    o, d = _bump_floor_rays(tex, 40000 if which != "procedural_stone" else 16000, 3)
+    o, d = _bump_floor_rays(tex, 40000 if which not in ("procedural_stone", "stone") else 16000, 3)
     hw, lw, nw = BackendScene(orc, objs).intersect_batch(0, o, d)
     sc = cg.Scene(objs)
     hg, lg, ng = sc.intersect_rays(0, o, d)

@@ -43,6 +43,42 @@ def test_photon_pass_matches_reference_golden(gpu_ready, case):
     assert np.array_equal(r2["image"], r["image"])
 
 
+@pytest.mark.parametrize("case", make_golden.photon_cases()[:2], ids=[c[0] for c in make_golden.photon_cases()[:2]])
+def test_pair_buffer_overflow_path_matches_reference_golden(gpu_ready, case):
+    """the pair buffer's overflow path.  pair_cap (a cgrt_photons field, 0 = automatic) is forced far below
+    the pairs one default batch produces, so the 64-bit pair count exceeds it, the batch is redone in halves -- several
+    times -- and grows back as radii shrink; the result must still be the compiled reference's, bit for bit."""
+    import cgraytracing_amd as cg
+    name, mk, cam, W, H, spp, nph = case
+    g = np.load(os.path.join(GOLD, "ppm_%s.npz" % name))
+    with cg.Scene(mk()) as sc:
+        base = sc.ppm_render(W, H, spp, cam(), 5, 12345, nphotons=nph)
+        assert base["n_batch_halvings"] == 0 and base["n_pairs"] > 40000
+        r = sc.ppm_render(W, H, spp, cam(), 5, 12345, nphotons=nph, want_hitpoints=True, pair_cap=max(2000, base["n_pairs"] // 40))
+    assert r["n_batch_halvings"] >= 3, r["n_batch_halvings"]
+    assert r["n_pairs"] >= base["n_pairs"]  # smaller batches test against fresher (smaller) radii only at batch starts
+    got = _canon(r["hp"], spp)
+    assert np.array_equal(got[:, :11], g["hp"][:, :11]) and np.array_equal(got[:, 11:16], g["hp"][:, 11:16])
+    assert np.array_equal(r["image"], g["image"]) and np.array_equal(base["image"], g["image"])
+
+
+def test_initial_radius_field(gpu_ready, orc):
+    """cgrt_photons.initial_radius: 0 is the reference's committed 200/768 (main.cpp:84,183); the same value passed
+    explicitly gives the identical image; a host mirroring a reference compiled for another `height` gets another radius,
+    hence another cell length (hash.h:25-26) and another image -- checked for sanity only (no reference build with another
+    height exists to pin it: parity unpinned for values other than 200/768)."""
+    import cgraytracing_amd as cg
+    W, H, nph = 48, 36, 20000
+    with cg.Scene(scenes.scene_c2()) as sc:
+        a = sc.ppm_render(W, H, 1, scenes.cam_pinhole(), 5, 12345, nphotons=nph)
+        b = sc.ppm_render(W, H, 1, scenes.cam_pinhole(), 5, 12345, nphotons=nph, initial_radius=200.0 / 768)
+        c = sc.ppm_render(W, H, 1, scenes.cam_pinhole(), 5, 12345, nphotons=nph, initial_radius=200.0 / 1080, want_hitpoints=True)
+    g = np.load(os.path.join(GOLD, "ppm_c2_48x36.npz"))
+    assert np.array_equal(a["image"], g["image"]) and np.array_equal(b["image"], a["image"])
+    assert not np.array_equal(c["image"], a["image"])
+    assert c["hp"][:, 14].max() <= (200.0 / 1080) ** 2 and np.isfinite(c["image"]).all() and c["image"].max() > 0
+
+
 def test_photon_pass_larger_vs_oracle(gpu_ready, orc):
     import cgraytracing_amd as cg
     objs = scenes.scene_c2()
