@@ -28,15 +28,22 @@ def global_row(j, stripe_rows, rank, nranks, row_offset=0):
     return ((j // stripe_rows) * nranks + rank) * stripe_rows + (j % stripe_rows)
 
 
-def assemble(gathered, height, stripe_rows, nranks):
-    """gathered: tensor [nranks, rows_local, W, C] (rank-major).  Returns [height, W, C] in global row order."""
-    if nranks <= 1:
+def assemble(gathered, height, stripe_rows, nshares, out=None):
+    """gathered: tensor [n, rows_local, W, C] (rank-major), the buffers of shares 0..n-1 of `nshares` (n == nshares when
+    every share has a rank).  Returns [height, W, C] in global row order; rows of shares nobody rendered are zero.
+    `out`: optional preallocated [per_share, nshares, S, W, C] scratch for the partial case."""
+    if nshares <= 1:
         return gathered[0][:height]
     n, rows_local, W, Cc = gathered.shape
-    per_rank = rows_local // stripe_rows
-    # [rank, stripe_in_rank, S, W, C] -> [stripe_in_rank, rank, S, W, C]: global stripe = k*nranks + rank
-    x = gathered.reshape(n, per_rank, stripe_rows, W, Cc).permute(1, 0, 2, 3, 4)
-    return x.reshape(per_rank * n * stripe_rows, W, Cc)[:height]
+    per = rows_local // stripe_rows
+    # [share, stripe_in_share, S, W, C] -> [stripe_in_share, share, S, W, C]: global stripe = k*nshares + share
+    x = gathered.reshape(n, per, stripe_rows, W, Cc).permute(1, 0, 2, 3, 4)
+    if n < nshares:
+        if out is None:
+            out = gathered.new_zeros((per, nshares, stripe_rows, W, Cc))
+        out[:, :n] = x
+        x = out
+    return x.reshape(per * nshares * stripe_rows, W, Cc)[:height]
 
 
 class StripedRenderer:
@@ -44,9 +51,13 @@ class StripedRenderer:
 
     render_local(rows_local, stripe) -> tensor [rows_local, W, 3] produces this rank's stripes; by default it
     launches cgrt_trace_grid on this rank's GPU.  It is injectable so the sharding / gather logic can be
-    exercised with the gloo backend on CPU-only machines."""
+    exercised with the gloo backend on CPU-only machines.
 
-    def __init__(self, width, height, stripe_rows=8, group=None, render_local=None, device=None):
+    nshares (default: the number of ranks) is the number of shares the stripes are dealt to; rank r renders share r.
+    nshares > ranks renders only the first `ranks` shares of the frame (weak scaling of a frame defined on nshares GPUs:
+    every GPU's work and ray mix are those of the full configuration whatever the number of GPUs present)."""
+
+    def __init__(self, width, height, stripe_rows=8, group=None, render_local=None, device=None, nshares=None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -58,14 +69,25 @@ class StripedRenderer:
         if stripe_rows % 8:
             raise ValueError("stripe_rows must be a multiple of 8 (kernel tile height)")
         self.stripe_rows = int(stripe_rows)
-        self.rows_local = local_rows(self.H, self.stripe_rows, self.rank, self.nranks)
+        self.nshares = int(nshares) if nshares else self.nranks
+        if self.nshares < self.nranks:
+            raise ValueError("nshares must be >= the number of ranks")
+        self.rows_local = local_rows(self.H, self.stripe_rows, self.rank, self.nshares)
         self.render_local = render_local
         self.device = device
         self._gather_buf = None
+        self._partial = None
 
     @property
     def stripe(self):
-        return (self.stripe_rows, self.rank, self.nranks) if self.nranks > 1 else None
+        return (self.stripe_rows, self.rank, self.nshares) if self.nshares > 1 else None
+
+    def _assemble(self, gathered):
+        if gathered.shape[0] < self.nshares:  # scratch for the partial frame: the rows of absent shares stay zero
+            shape = (gathered.shape[1] // self.stripe_rows, self.nshares, self.stripe_rows) + tuple(gathered.shape[2:])
+            if self._partial is None or tuple(self._partial.shape) != shape or self._partial.device != gathered.device:
+                self._partial = gathered.new_zeros(shape)
+        return assemble(gathered, self.H, self.stripe_rows, self.nshares, out=self._partial)
 
     def gather(self, local):
         """One gather of the local [rows_local, W, 3] blocks to rank 0; returns the assembled frame on rank 0
@@ -73,7 +95,7 @@ class StripedRenderer:
         import torch
 
         if self.nranks == 1:
-            return local[: self.H]
+            return local[: self.H] if self.nshares == 1 else self._assemble(local[None])
         if local.is_cuda and self.dist.get_backend(self.group) == "gloo":
             local = local.cpu()  # rehearsal on machines without RCCL-capable peers: gloo gathers host tensors
         if self.rank == 0:
@@ -83,7 +105,7 @@ class StripedRenderer:
                                                device=local.device)
             lst = list(self._gather_buf.unbind(0))
             self.dist.gather(local, gather_list=lst, dst=0, group=self.group)
-            return assemble(self._gather_buf, self.H, self.stripe_rows, self.nranks)
+            return self._assemble(self._gather_buf)
         self.dist.gather(local, gather_list=None, dst=0, group=self.group)
         return None
 
