@@ -42,4 +42,26 @@ __device__ __forceinline__ double det3(V3 a, V3 b, V3 c) {
 }
 __device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 
+// A record of the uploaded scene read at a WAVE-UNIFORM address (a tree / height-field / Bezier header picked by a
+// readfirstlane'd index).  The scene is immutable while a kernel runs, so the load goes through the constant address space:
+// the compiler then issues scalar loads (s_load_dwordx4/x8 into SGPRs) whatever stores surround it.  Without this it falls
+// back to per-lane vector loads of the same address as soon as the kernel stores to global memory before the load on some
+// path -- measured on the opaque-mesh kernel: +16 % vector-memory instructions, the 40-byte TreeRec and 64-byte HFieldRec
+// held in VGPRs, frame 49.8 -> 58.5 ms.
+template <class T>
+__device__ __forceinline__ T load_uniform(const T *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "dword-copyable record");
+    typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
+    ConstWords q = (ConstWords)p;
+    T out;
+    uint32_t *o = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) o[i] = q[i];
+    return out;
+#else
+    return *p;
+#endif
+}
+
 #endif

@@ -22,16 +22,19 @@ struct HitpointSink {
     unsigned long long cap;
 };
 
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256>
-__global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
-                                                             uint32_t *__restrict__ nhit_out,
-                                                             unsigned long long *__restrict__ counters,
-                                                             HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
+// The body of the eye pass for one workgroup.  HEAVY selects how the waves get their work (see GridParams): false -- each
+// wave owns one wave tile (16x4 pixels, one per lane) and every lane runs its pixel's samples; true -- the waves serve the
+// queue of heavy-tile items, lanes drawing (pixel, sample) units.  tile_block / tile_grid: this workgroup's index among the
+// tile workgroups and their number (the launch may put heavy workgroups in front of them).
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS, int NT, bool HEAVY>
+__device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const GridParams &g, float *__restrict__ rgb,
+                                                uint32_t *__restrict__ nhit_out, unsigned long long *__restrict__ counters,
+                                                const HitpointSink &hps, int tile_block, int tile_grid) {
     using TG = TileGeom<NT>;
-    // LDS carve-up: [ pending-ray levels (GLASS) -- aliased by the output tile at the end | objs ]
+    const long long tl_t0 = g.timeline ? wall_clock64() : 0;
+    // LDS carve-up: [ pending-ray levels (GLASS) | objs | Bezier scratch | node cache ]
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    float *ltile = reinterpret_cast<float *>(lds_raw);
-    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? TG::stack_bytes : TG::tile_bytes));  // n_objs records
+    ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? TG::stack_bytes : 0));  // n_objs records
     // BEZ: one BezLds per wave behind the object list (16-byte aligned: ObjRec is 128 B)
     unsigned char *lrest = reinterpret_cast<unsigned char *>(lobjs + sc.n_objs);
     LdsAux aux;
@@ -55,76 +58,170 @@ __global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trac
         for (int k = threadIdx.x; k < n16; k += NT) dst[k] = src[k];
     }
     __syncthreads();
+    const long long cost_t0 = g.probe ? (long long)clock64() : 0;
 
-    // which tile, and -- when a tile's samples are split over several workgroups -- which chunk of its samples
-    const int tile_blocks = (int)gridDim.x / g.chunks;
-    const int chunk = (int)blockIdx.x / tile_blocks;
-    int tile_x, tile_y;
-    if (!tile_of_block(g, (int)blockIdx.x % tile_blocks, tile_x, tile_y, TG::W, TG::H)) return;  // whole workgroup (no later barrier is missed)
-    const int s_end = (g.chunks > 1) ? ((chunk + 1) * g.chunk_spp < g.spp ? (chunk + 1) * g.chunk_spp : g.spp) : g.spp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // wave = 16x4 pixels, 2x2 waves per workgroup (8x8 per wave measured: meshes equal, C2 7 % slower)
-    const int lx = (wave & 1) * 16 + (lane & 15);
-    const int ly = (wave >> 1) * 4 + (lane >> 4);
-    const int w = tile_x * TG::W + lx;
-    const int j = tile_y * TG::H + ly;  // local row
-    const int h = global_row(g, j);
-    const bool live = (w < g.W) && (j < g.rows) && (h < g.H);
-
+    const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW, wtiles_y = (g.rows + kWaveTileH - 1) / kWaveTileH;
     const V3 camorg = mk(g.cam[0], g.cam[1], g.cam[2]);
-    // main.cpp:188-189,198,203
-    const double px = (2.0 * ((double)w / g.W) - 1) * g.half_width;
-    const double py = (2.0 * ((double)h / g.H) - 1) * g.half_width * g.H / g.W;
-    const V3 pdir = normalized(mk(px, py, 0) - camorg);
-    const V3 pof = pdir * ((g.focus_plane - camorg.z) / pdir.z) + camorg;
-    const uint64_t k_pix = pixel_key(g.seed, (uint64_t)h * (uint64_t)g.W + (uint64_t)w);
+    // HEAVY: this launch's waves serve the queue of heavy-tile items instead of owning a tile each (its own kernel variant:
+    // the per-unit pixel state costs registers the tile variant does not have to spare).
+    constexpr bool heavy = HEAVY;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    // ---- the pixel a lane is working on: fixed for a tile's wave, set per unit for a heavy wave ----
+    int wx = 0, wy = 0, chunk = 0, s_end = 0;
+    bool have_tile = false;
+    int w = 0, j = 0, h = 0;
+    bool live = false;
+    V3 pdir = mk(0, 0, 1), pof = mk(0, 0, 0);
+    uint64_t k_pix = 0;
+    auto set_pixel = [&](int lx, int ly) {  // lane-local pixel (lx, ly) of wave tile (wx, wy); main.cpp:188-189,198,203
+        w = wx * kWaveTileW + lx;
+        j = wy * kWaveTileH + ly;  // local row
+        h = global_row(g, j);
+        live = have_tile && (w < g.W) && (j < g.rows) && (h < g.H);
+        const double px = (2.0 * ((double)w / g.W) - 1) * g.half_width;
+        const double py = (2.0 * ((double)h / g.H) - 1) * g.half_width * g.H / g.W;
+        pdir = normalized(mk(px, py, 0) - camorg);
+        pof = pdir * ((g.focus_plane - camorg.z) / pdir.z) + camorg;
+        k_pix = pixel_key(g.seed, (uint64_t)h * (uint64_t)g.W + (uint64_t)w);
+    };
+    if (!heavy) {
+        // Natural order: a workgroup's waves are the 2x2 wave tiles of a 32x8 tile (tile_of_block: XCD-aware or row-major);
+        // 8x8 per wave measured: meshes equal, C2 7 % slower.  When a tile's samples are split over several workgroups
+        // (chunks > 1) the chunk index comes from the block index too.
+        const int nb = tile_block;
+        const int tile_blocks = tile_grid / g.chunks;
+        chunk = nb / tile_blocks;
+        int tile_x, tile_y;
+        if (!tile_of_block(g, nb % tile_blocks, tile_x, tile_y, TG::W, TG::H)) return;  // whole workgroup (no later barrier is missed)
+        wx = tile_x * (TG::W / kWaveTileW) + (NT == 256 ? (wave & 1) : 0);
+        wy = tile_y * (TG::H / kWaveTileH) + (NT == 256 ? (wave >> 1) : 0);
+        have_tile = wx < wtiles_x && wy < wtiles_y;
+        // a heavy tile is rendered by the heavy workgroups: its wave stands down here
+        if (have_tile && g.hidx && g.hidx[wy * wtiles_x + wx] >= 0) have_tile = false;
+        s_end = (g.chunks > 1) ? ((chunk + 1) * g.chunk_spp < g.spp ? (chunk + 1) * g.chunk_spp : g.spp) : g.spp;
+        set_pixel(lane & 15, lane >> 4);
+    }
     uint64_t k_smp = 0;  // key of the sample whose ray tree this lane is tracing
 
     double acc_r = 0, acc_g = 0, acc_b = 0;
     uint32_t my_hits = 0, my_rays = 0, my_nodes = 0, my_tris = 0, wave_iters = 0;
-    uint32_t hp_seq = 0;  // HPS: index of the next Hitpoint within the current sample's ray tree (emission order)
+    uint32_t hp_seq = 0;  // index of the next Hitpoint within the current sample's ray tree (emission order)
 
     Pending deep[2];   // third stack level (scratch; indexed dynamically so that it stays out of registers)
     Pending sib;       // refracted sibling of a leaf-level glass hit (registers)
     bool sib_valid = false;
-    unsigned char *lslot = lds_raw;  // level L, field f of this thread: lslot + L*TG::level_bytes + (f*256 + tid)*8
+    unsigned char *lslot = lds_raw;  // level L, field f of this thread: lslot + L*TG::level_bytes + (f*NT + tid)*8
     int sp = 0;
     int s = (g.chunks > 1) ? chunk * g.chunk_spp : 0;  // next sample to start
     bool have = false;
     V3 o = camorg, d = pdir, adj = mk(1, 1, 1);
     int depth_left = 0;
     uint32_t path = 1;
+    // heavy waves: the item units are being drawn from (wave-uniform) and the lane's own unit
+    int unit_next = 0, unit_end = 0, hrank = 0;
+    int unit_pix = 0, unit_smp = 0, unit_rank = 0;
+    bool unit_open = false;
 
-    while (true) {
-        if (!have) {
-            if (live && s < s_end) {
-                // start the next sample of this lane's pixel (main.cpp:204-209)
-                k_smp = sample_key(k_pix, (uint64_t)(g.sample_offset + s));
-                if (DOF) {
-                    Stream rs(k_smp);  // purpose 0: the lens stream's key is the sample key
-                    double sx, sy;
-                    while (true) {  // uniform_sampling_circle, sampling.h:35-43
-                        double ux, uy;
-                        rs.pair(ux, uy);
-                        sx = ux * 2.0 - 1;
-                        sy = uy * 2.0 - 1;
-                        if (sx * sx + sy * sy < 1) break;
-                    }
-                    o = camorg + mk(sx, sy, 0) * g.lens_radius;
-                    d = normalized(pof - o);
-                } else {
-                    o = camorg;
-                    d = pdir;
-                }
-                adj = mk(1, 1, 1);
-                depth_left = g.max_depth;
-                path = 1;
-                s++;
-                hp_seq = 0;
-                have = true;
+    auto start_sample = [&](int smp) {  // main.cpp:204-209
+        k_smp = sample_key(k_pix, (uint64_t)(g.sample_offset + smp));
+        if (DOF) {
+            Stream rs(k_smp);  // purpose 0: the lens stream's key is the sample key
+            double sx, sy;
+            while (true) {  // uniform_sampling_circle, sampling.h:35-43
+                double ux, uy;
+                rs.pair(ux, uy);
+                sx = ux * 2.0 - 1;
+                sy = uy * 2.0 - 1;
+                if (sx * sx + sy * sy < 1) break;
             }
+            o = camorg + mk(sx, sy, 0) * g.lens_radius;
+            d = normalized(pof - o);
+        } else {
+            o = camorg;
+            d = pdir;
         }
-        if (__ballot(have) == 0ull) break;  // every lane of the wave has drained its pixel
+        adj = mk(1, 1, 1);
+        depth_left = g.max_depth;
+        path = 1;
+        hp_seq = 0;
+        have = true;
+    };
+
+    // heavy waves: `hrank`, wx, wy and [unit_next, unit_end) describe the item the wave is currently drawing units from
+    // (wave-uniform); a lane remembers the item of the unit it is tracing in unit_rank (the wave may have moved on)
+    bool queue_empty = false;
+    unsigned item_ahead = 0, n_items_total = 0;
+    if (heavy) {
+        n_items_total = load_uniform(g.plan) * (unsigned)g.items_per_tile;
+        if (lane == 0) item_ahead = atomicAdd(&g.plan[2], 1u);
+    }
+    while (true) {
+        if (heavy) {
+            // A lane without a ray closes its unit (how many Hitpoints it produced) and takes the next one: unit u of an item
+            // is sample u / 64 of pixel u % 64 of the item's tile, so the lanes of a wave keep working on neighbouring pixels
+            // of one sample.  When the item runs dry the wave takes the next item from the queue at once -- lanes still
+            // tracing units of the old item carry on -- so lanes idle only when the whole queue is empty.
+            const bool want = !have;
+            const unsigned long long m = __ballot(want);
+            if (m != 0ull) {
+                if (want && unit_open) {
+                    g.dcnt[((size_t)unit_rank * g.spp + unit_smp) * 64 + unit_pix] = (unsigned char)hp_seq;
+                    unit_open = false;
+                }
+                if (unit_next >= unit_end && !queue_empty) {
+                    // the item fetched ahead (its atomic has been in flight while the previous item was traced) ...
+                    const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)item_ahead);
+                    // ... and the one after it is requested now
+                    if (lane == 0) item_ahead = atomicAdd(&g.plan[2], 1u);
+                    if (item >= n_items_total) {
+                        queue_empty = true;
+                    } else {
+                        hrank = (int)(item / (unsigned)g.items_per_tile);
+                        const uint32_t wt = load_uniform(g.order + hrank);
+                        wx = (int)(wt % (uint32_t)wtiles_x);
+                        wy = (int)(wt / (uint32_t)wtiles_x);
+                        have_tile = true;
+                        unit_next = (int)(item % (unsigned)g.items_per_tile) * g.units_per_item;
+                        unit_end = unit_next + g.units_per_item;
+                        if (unit_end > 64 * g.spp) unit_end = 64 * g.spp;
+                    }
+                }
+                const int u = unit_next + (int)__popcll(m & lanes_below);
+                unit_next += (int)__popcll(m);  // lanes that drew beyond unit_end draw again from the next item
+                if (want && u < unit_end) {
+                    unit_pix = u & 63;
+                    unit_smp = u >> 6;
+                    unit_rank = hrank;
+                    // the pixel's camera constants come from the table pixel_const_kernel filled (five fp64 divisions, a square
+                    // root and two hash rounds per pixel: a third of a sphere-scene sample if redone for every unit)
+                    w = wx * kWaveTileW + (unit_pix & 15);
+                    j = wy * kWaveTileH + (unit_pix >> 4);
+                    h = global_row(g, j);
+                    live = (w < g.W) && (j < g.rows) && (h < g.H);
+                    if (live) {
+                        const double *pc = g.pconst + (size_t)unit_rank * (7 * 64) + unit_pix;
+                        pdir = mk(pc[0 * 64], pc[1 * 64], pc[2 * 64]);
+                        pof = mk(pc[3 * 64], pc[4 * 64], pc[5 * 64]);
+                        k_pix = (uint64_t)__double_as_longlong(pc[6 * 64]);
+                        start_sample(unit_smp);
+                        unit_open = true;
+                    }
+                }
+            }
+            if (__ballot(have) == 0ull) {
+                if (queue_empty && unit_next >= unit_end) break;  // nothing left anywhere
+                continue;                                         // drew nothing traceable (item boundary, pixels outside the image)
+            }
+        } else {
+            if (!have && live && s < s_end) {
+                // start the next sample of this lane's pixel
+                start_sample(s);
+                s++;
+            }
+            if (__ballot(have) == 0ull) break;  // every lane of the wave has drained its pixel
+        }
         wave_iters++;
         // All 64 lanes enter the scene walk together (lanes without a ray carry on == false): the object list
         // is wave-uniform, so its control flow stays scalar.
@@ -153,9 +250,17 @@ __global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trac
                 if (refl < kEps && transp < kEps) {
                     // diffuse: the reference stores Hitpoint{f*adj,...} (main.cpp:85-100); we accumulate it
                     const V3 hf = mulv(f, adj);
-                    acc_r += hf.x;
-                    acc_g += hf.y;
-                    acc_b += hf.z;
+                    if (heavy) {
+                        // deferred: the value is added in deferred_sum_kernel, in this (sample, emission) position
+                        double *q = g.dvals + ((((size_t)unit_rank * g.spp + unit_smp) * g.maxhp + hp_seq) * 64 + unit_pix) * 3;
+                        q[0] = hf.x;
+                        q[1] = hf.y;
+                        q[2] = hf.z;
+                    } else {
+                        acc_r += hf.x;
+                        acc_g += hf.y;
+                        acc_b += hf.z;
+                    }
                     my_hits++;
                     if (HPS) {
                         const unsigned long long k = atomicAdd(hps.count, 1ull);
@@ -169,8 +274,8 @@ __global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trac
                             q[9] = (double)((((unsigned long long)(s - 1) * (unsigned long long)g.W * g.rows +
                                               (unsigned long long)j * g.W + w) << 4) | (unsigned long long)hp_seq);
                         }
-                        hp_seq++;
                     }
+                    if (HPS || heavy) hp_seq++;
                 } else if (depth_left > 1) {
                     if (transp < kEps) {
                         // mirror, main.cpp:129-134
@@ -264,11 +369,23 @@ __global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trac
                 have = true;
             }
         }
-    }
+    }  // ray loop
 
-    if (g.chunks > 1) {
-        // split samples: this workgroup's raw fp64 sums; finalize_chunks_kernel adds the chunks in order
-        if ((w < g.W) && (j < g.rows)) {  // rows past the image (stripe padding) carry zero sums
+    if (g.probe) {
+        // cost probe: nothing of the image is stored; the wave leaves what its tile cost and the tile's number
+        if (lane == 0 && have_tile) {
+            const long long dt = (long long)clock64() - cost_t0;
+            const uint32_t wt = (uint32_t)(wy * wtiles_x + wx);
+            g.cost[wt] = dt > 0 ? (dt < 0xffffffffll ? (uint32_t)dt : 0xffffffffu) : 1u;
+            g.ids[wt] = wt;
+        }
+        return;  // no counters: the render launch that follows counts these rays
+    }
+    if (heavy) {
+        // nothing to store: deferred_sum_kernel writes the heavy tiles' pixels
+    } else if (g.chunks > 1) {
+        // split samples: this wave's raw fp64 sums; finalize_chunks_kernel adds the chunks in order
+        if (have_tile && (w < g.W) && (j < g.rows)) {  // rows past the image (stripe padding) carry zero sums
             const size_t px = ((size_t)chunk * g.rows + (size_t)j) * g.W + (size_t)w;
             g.partial[3 * px + 0] = acc_r;
             g.partial[3 * px + 1] = acc_g;
@@ -276,24 +393,42 @@ __global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trac
             if (g.partial_nhit) g.partial_nhit[px] = my_hits;
         }
     } else {
-    // ---- coalesced store through LDS: 32 px x 3 floats = 384 contiguous bytes per tile row ----
-    if (GLASS) __syncthreads();  // every wave is done with the pending-ray levels the tile aliases
-    ltile[ly * (TG::W * 3) + lx * 3 + 0] = (float)(acc_r * g.inv_spp_total);
-    ltile[ly * (TG::W * 3) + lx * 3 + 1] = (float)(acc_g * g.inv_spp_total);
-    ltile[ly * (TG::W * 3) + lx * 3 + 2] = (float)(acc_b * g.inv_spp_total);
-    __syncthreads();
-    for (int k = threadIdx.x; k < TG::H * TG::W * 3; k += NT) {
-        const int row = k / (TG::W * 3), col = k % (TG::W * 3);
-        const int jj = tile_y * TG::H + row;
-        const int ww = tile_x * TG::W + col / 3;
-        if (jj < g.rows && ww < g.W) {
-            float *dst = rgb + ((size_t)jj * g.W + tile_x * TG::W) * 3 + col;
-            *dst = g.accumulate ? *dst + ltile[k] : ltile[k];  // progressive passes add into the fp32 frame
+        // ---- store: the wave's 16x4 pixels are 4 rows of 48 contiguous floats; lane l of pass k writes float k*64 + l of
+        // the tile, fetched from the lane that owns that pixel (three ds_bpermute shuffles per pass, no LDS, no barrier).
+        // A store instruction then covers 256 contiguous bytes of a row (192 + 64 of the next).
+        const float v0 = (float)(acc_r * g.inv_spp_total), v1 = (float)(acc_g * g.inv_spp_total),
+                    v2 = (float)(acc_b * g.inv_spp_total);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int idx = k * 64 + lane;
+            const int row = idx / (kWaveTileW * 3), c = idx % (kWaveTileW * 3);
+            const int src = row * kWaveTileW + c / 3, ch = c % 3;
+            const float a0 = __shfl(v0, src), a1 = __shfl(v1, src), a2 = __shfl(v2, src);
+            const float v = ch == 0 ? a0 : (ch == 1 ? a1 : a2);
+            const int jj = wy * kWaveTileH + row, ww = wx * kWaveTileW + c / 3;
+            if (have_tile && jj < g.rows && ww < g.W) {
+                float *dst = rgb + ((size_t)jj * g.W + ww) * 3 + ch;
+                *dst = g.accumulate ? *dst + v : v;  // progressive passes add into the fp32 frame
+            }
         }
-    }
-    if (nhit_out && (w < g.W) && (j < g.rows)) nhit_out[(size_t)j * g.W + w] = my_hits;
+        if (nhit_out && have_tile && (w < g.W) && (j < g.rows)) nhit_out[(size_t)j * g.W + w] = my_hits;
     }
 
+    if (g.timeline) {  // development aid: when and where this workgroup ran
+        __shared__ unsigned int tl_rays;
+        if (threadIdx.x == 0) tl_rays = 0;
+        __syncthreads();
+        atomicAdd(&tl_rays, my_rays);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long *q = g.timeline + 4 * (size_t)blockIdx.x;
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            q[0] = (unsigned long long)tl_t0;
+            q[1] = (unsigned long long)wall_clock64();
+            q[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            q[3] = (unsigned long long)(wx & 0xffff) | ((unsigned long long)(wy & 0xffff) << 16) | ((unsigned long long)tl_rays << 32);
+        }
+    }
     if (counters) {
         // wave reduction, then one atomic per wave and counter
         unsigned long long r = my_rays, hh = my_hits, nn = my_nodes, tt = my_tris;
@@ -317,11 +452,42 @@ __global__ __launch_bounds__(NT, BEZ ? 3 : ((GLASS && TREES) ? 3 : 4)) void trac
     }
 }
 
+// One launch = tile workgroups only (probe, image order, Hitpoint capture) ...
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256>
+__global__ __launch_bounds__(NT, BEZ ? 3 : (TREES ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+                                                             uint32_t *__restrict__ nhit_out,
+                                                             unsigned long long *__restrict__ counters,
+                                                             HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
+    trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, HPS, NT, false>(sc, g, rgb, nhit_out, counters, hps, (int)blockIdx.x,
+                                                                        (int)gridDim.x);
+}
+// ... or the scheduled form: the first g.heavy_blocks workgroups serve the heavy tiles' unit queue, the others are the tile
+// workgroups.  Two bodies in one kernel: the dispatcher starts workgroups in index order, so the heavy work starts first and
+// tile workgroups take over the slots as the heavy waves retire -- no seam between two launches.  Each body keeps its own
+// register allocation (the paths are disjoint); the kernel's register and scratch sizes are the larger of the two.
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, int NT = 256>
+__global__ __launch_bounds__(NT, BEZ ? 3 : (TREES ? 3 : 4)) void trace_grid_sched_kernel(DeviceScene sc, GridParams g,
+                                                                                         float *__restrict__ rgb,
+                                                                                         uint32_t *__restrict__ nhit_out,
+                                                                                         unsigned long long *__restrict__ counters) {
+    const HitpointSink none{nullptr, nullptr, 0};
+    if ((int)blockIdx.x < g.heavy_blocks)
+        trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, counters, none, 0, 1);
+    else
+        trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, false>(sc, g, rgb, nhit_out, counters, none,
+                                                                              (int)blockIdx.x - g.heavy_blocks,
+                                                                              (int)gridDim.x - g.heavy_blocks);
+}
+
 // CGRT_GRID_SPLIT_SAMPLES, second step: chunk sums added in chunk order, scaled, rounded once to fp32.
 __global__ void finalize_chunks_kernel(GridParams g, float *__restrict__ rgb, uint32_t *__restrict__ nhit_out) {
     const size_t npx = (size_t)g.rows * g.W;
     const size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (px >= npx) return;
+    if (g.hidx) {  // pixels of heavy tiles are written by deferred_sum_kernel (their chunk sums do not exist)
+        const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW;
+        if (g.hidx[(int)((px / g.W) / kWaveTileH) * wtiles_x + (int)((px % g.W) / kWaveTileW)] >= 0) return;
+    }
     double r = 0, gg = 0, b = 0;
     uint32_t hits = 0;
     for (int c = 0; c < g.chunks; c++) {
@@ -339,6 +505,119 @@ __global__ void finalize_chunks_kernel(GridParams g, float *__restrict__ rgb, ui
         dst[0] = fr; dst[1] = fg; dst[2] = fb;
     }
     if (nhit_out) nhit_out[px] = hits;
+}
+
+// ---- cost-aware scheduling: plan and ordered sum (GridParams, "Cost-aware scheduling") ------------------------------------
+// One workgroup.  cost_sorted: the wave tiles' probe costs, descending; order: their numbers.  A wave tile is HEAVY when its
+// cost exceeds total / divisor -- divisor = wave slots of the chip x a constant, i.e. when the tile alone would occupy a wave
+// slot for more than 1/constant of the frame's ideal duration -- at most kmax of them (what the deferred buffers hold).
+// plan[0] = K, plan[1] = threshold, plan[2] = 0 (the item queue's head); hidx[wave tile] = rank for the K heavy ones.
+__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ cost_sorted, const uint32_t *__restrict__ order,
+                                                    int n, unsigned kmax, unsigned long long divisor, uint32_t *__restrict__ plan,
+                                                    int32_t *__restrict__ hidx) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned k_heavy;
+    unsigned long long t = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) t += cost_sorted[i];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long thr = part[0] / divisor;
+        if (thr < 1) thr = 1;
+        int lo = 0, hi = n;  // first index whose cost is <= thr (the list is descending)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((unsigned long long)cost_sorted[mid] > thr) lo = mid + 1; else hi = mid;
+        }
+        unsigned k = (unsigned)lo;
+        if (k > kmax) k = kmax;
+        k_heavy = k;
+        plan[0] = k;
+        plan[1] = (uint32_t)(thr > 0xffffffffull ? 0xffffffffull : thr);
+        plan[2] = 0;
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < k_heavy; i += 1024) hidx[order[i]] = (int32_t)i;
+}
+
+// The per-pixel camera constants of the heavy tiles (what set_pixel computes), one 64-thread workgroup per heavy tile.
+__global__ __launch_bounds__(64) void pixel_const_kernel(GridParams g) {
+    const unsigned hr = blockIdx.x;
+    if (hr >= g.plan[0]) return;
+    const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW;
+    const uint32_t wt = g.order[hr];
+    const int p = threadIdx.x;
+    const int w = (int)(wt % (uint32_t)wtiles_x) * kWaveTileW + (p & 15), j = (int)(wt / (uint32_t)wtiles_x) * kWaveTileH + (p >> 4);
+    const int h = global_row(g, j);
+    const V3 camorg = mk(g.cam[0], g.cam[1], g.cam[2]);
+    // main.cpp:188-189,198,203 -- the same expressions as set_pixel
+    const double px = (2.0 * ((double)w / g.W) - 1) * g.half_width;
+    const double py = (2.0 * ((double)h / g.H) - 1) * g.half_width * g.H / g.W;
+    const V3 pdir = normalized(mk(px, py, 0) - camorg);
+    const V3 pof = pdir * ((g.focus_plane - camorg.z) / pdir.z) + camorg;
+    const uint64_t k_pix = pixel_key(g.seed, (uint64_t)h * (uint64_t)g.W + (uint64_t)w);
+    double *pc = g.pconst + (size_t)hr * (7 * 64) + p;
+    pc[0 * 64] = pdir.x; pc[1 * 64] = pdir.y; pc[2 * 64] = pdir.z;
+    pc[3 * 64] = pof.x;  pc[4 * 64] = pof.y;  pc[5 * 64] = pof.z;
+    pc[6 * 64] = __longlong_as_double((long long)k_pix);
+}
+
+// One 64-thread workgroup per heavy tile, one thread per pixel: the pixel's Hitpoint values added sample by sample, in
+// emission order within a sample -- the order of the reference's serial loop (main.cpp:204-209 around main.cpp:85-100).
+// The additions are a serial chain but the loads are not: the counts and the first value of eight samples are requested
+// together (a sample rarely has more than one Hitpoint outside glass), further values of a sample all at once.
+__global__ __launch_bounds__(64) void deferred_sum_kernel(GridParams g, float *__restrict__ rgb, uint32_t *__restrict__ nhit_out) {
+    const unsigned hr = blockIdx.x;
+    if (hr >= g.plan[0]) return;
+    const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW;
+    const uint32_t wt = g.order[hr];
+    const int p = threadIdx.x;
+    const int w = (int)(wt % (uint32_t)wtiles_x) * kWaveTileW + (p & 15), j = (int)(wt / (uint32_t)wtiles_x) * kWaveTileH + (p >> 4);
+    if (w >= g.W || j >= g.rows) return;
+    double r = 0, gg = 0, b = 0;
+    uint32_t hits = 0;
+    if (global_row(g, j) < g.H) {  // rows past the image (stripe padding) had no units: zero
+        constexpr int B = 8;
+        for (int s0 = 0; s0 < g.spp; s0 += B) {
+            int c[B];
+            double v[B][3];
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const size_t us = (size_t)hr * g.spp + (s0 + i < g.spp ? s0 + i : g.spp - 1);
+                c[i] = s0 + i < g.spp ? (int)g.dcnt[us * 64 + p] : 0;
+                const double *q = g.dvals + (us * g.maxhp * 64 + p) * 3;
+                v[i][0] = q[0]; v[i][1] = q[1]; v[i][2] = q[2];  // slot 0 always exists (read even when the count is 0)
+            }
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                if (c[i] > 0) {
+                    r += v[i][0];
+                    gg += v[i][1];
+                    b += v[i][2];
+                    const size_t us = (size_t)hr * g.spp + s0 + i;
+                    for (int q = 1; q < c[i]; q++) {
+                        const double *x = g.dvals + ((us * g.maxhp + q) * 64 + p) * 3;
+                        r += x[0];
+                        gg += x[1];
+                        b += x[2];
+                    }
+                    hits += (uint32_t)c[i];
+                }
+            }
+        }
+    }
+    const float fr = (float)(r * g.inv_spp_total), fg = (float)(gg * g.inv_spp_total), fb = (float)(b * g.inv_spp_total);
+    float *dst = rgb + ((size_t)j * g.W + w) * 3;
+    if (g.accumulate) {
+        dst[0] += fr; dst[1] += fg; dst[2] += fb;
+    } else {
+        dst[0] = fr; dst[1] = fg; dst[2] = fb;
+    }
+    if (nhit_out) nhit_out[(size_t)j * g.W + w] = hits;
 }
 
 // function-level probe: one object, n rays (cgrt_intersect_rays)

@@ -16,12 +16,38 @@ struct GridParams {
     int32_t chunks, chunk_spp;
     double *partial;
     uint32_t *partial_nhit;
+    // Cost-aware scheduling (cgrt_hip.hip, "probe -> sort -> plan -> render -> ordered sum").  The unit of
+    // bookkeeping is a WAVE TILE of 16x4 pixels, numbered wy * ceil(W/16) + wx over the local rows.
+    //   probe != 0 : trace this launch's first sample only to measure it -- nothing is stored except cost[wave tile] =
+    //                shader-clock ticks the wave spent on it and ids[wave tile] = wave tile (the sort's payload).
+    //   render     : order[] = wave tiles by descending cost, plan[0] = K = how many of them are HEAVY, hidx[wave tile] =
+    //                rank among the heavy ones or -1.  A first launch (the HEAVY kernel variant, heavy_blocks workgroups that
+    //                loop until the queue is empty) serves the heavy tiles through a queue of ITEMS (plan[2] = next item; item = heavy tile rank * items_per_tile + part): an item is
+    //                units_per_item (pixel, sample) UNITS of one heavy tile, which the lanes of the wave take one after
+    //                another as they become free, so a heavy tile is spread over many waves on many CUs and no lane idles
+    //                while units remain.  Every Hitpoint value of a unit goes to dvals[rank][sample][emission index][pixel]
+    //                (dcnt = how many), and deferred_sum_kernel adds them per pixel in the reference's order -- sample by
+    //                sample, emission order within a sample -- so the fp64 sum is bit for bit the sequential one.  The
+    //                tile launch renders the other tiles in image order (waves whose tile is heavy stand down).
+    const uint32_t *order;
+    uint32_t *cost, *ids;
+    const int32_t *hidx;
+    uint32_t *plan;
+    double *dvals;
+    unsigned char *dcnt;
+    double *pconst;  // heavy tiles: per pixel {pdir(3), pof(3), bits of k_pix}, layout [rank][7][64], filled by pixel_const_kernel
+    int32_t probe, heavy_blocks, items_per_tile, units_per_item, maxhp;
+    // development aid (env CGRT_TIMELINE_FILE, cgrt_hip.hip): per workgroup {start, end (wall_clock64, 100 MHz), HW_ID | XCC_ID << 32,
+    // tile_x | tile_y << 16 | rays << 32}; nullptr in normal operation
+    unsigned long long *timeline;
     double inv_spp_total;
     uint64_t seed;
     double cam[3], half_width, focus_plane, lens_radius;
 };
 
 static constexpr int kTileW = 32, kTileH = 8, kThreads = 256;
+static constexpr int kWaveTileW = 16, kWaveTileH = 4;  // one pixel per lane
+static constexpr uint32_t kNoWaveTile = 0xffffffffu;
 static constexpr int kMaxObjs = 96;  // top-level objects staged in LDS (12 KiB)
 // Pending refracted rays (main.cpp:157) of a lane, newest last:
 //   * a glass hit whose children are leaves of the recursion (depth_left == 2) keeps the refracted child in
@@ -30,8 +56,8 @@ static constexpr int kMaxObjs = 96;  // top-level objects staged in LDS (12 KiB)
 //   * the first two other levels live in LDS: per level 9 doubles + one packed (depth, path) word per thread,
 //     layout [level][field][thread] (conflict-free), 2 x 19 456 B = 38 912 B per workgroup;
 //   * a third level (three nested glass hits with all siblings waiting) spills to scratch memory.
-// The output tile aliases the stack (dead by then), so stack + objs stays under 40 KiB and FOUR workgroups fit a
-// CU's 160 KiB: occupancy 4 waves/SIMD instead of 3, worth ~10 % on C2.
+// The output needs no LDS (each wave transposes its 16x4 tile with lane shuffles), so stack + objs stays under 40 KiB and
+// FOUR workgroups fit a CU's 160 KiB: occupancy 4 waves/SIMD instead of 3, worth ~10 % on C2.
 static constexpr int kPendDoubles = 9;
 static constexpr int kLdsLevels = 2;
 static constexpr size_t kLevelBytes = (size_t)kThreads * (kPendDoubles * sizeof(double) + sizeof(uint32_t));

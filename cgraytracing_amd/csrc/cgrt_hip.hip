@@ -12,6 +12,7 @@
 //     to fp32 and written through an LDS transpose as 384-byte contiguous row segments.
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/cgrt.h"
@@ -87,6 +89,17 @@ struct DeviceGuard {
 #define ON_DEVICE(dev)          \
     DeviceGuard dev_guard_(dev); \
     if (dev_guard_.err != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(dev_guard_.err))
+
+struct DevBuf {  // RAII for device temporaries: freed on every return path
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    void *release() { void *q = p; p = nullptr; return q; }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
 
 template <class T>
 static int upload(cgrt_scene *s, const std::vector<T> &v, const T **out) {
@@ -381,6 +394,8 @@ static GridVariant grid_variant(const cgrt_scene *s, const cgrt_camera *cam, con
     return v;
 }
 
+static bool glass_possible(const cgrt_scene *s, const cgrt_grid *grid) { return s->dev.has_glass != 0 && grid->max_depth > 1; }
+
 static int check_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *g) {
     if (!s || !cam || !g) return fail(CGRT_ERR_INVALID, "null argument");
     if (!s->committed) return fail(CGRT_ERR_INVALID, "scene not committed");
@@ -403,8 +418,9 @@ int cgrt_trace_grid_variant(const cgrt_scene *s, const cgrt_camera *cam, const c
     if (rc) return rc;
     if (!name || cap == 0) return fail(CGRT_ERR_INVALID, "null name buffer");
     const GridVariant v = grid_variant(s, cam, grid);
-    std::snprintf(name, cap, "trace_grid_kernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,HPS=0,NT=%d>", (int)v.trees,
-                  (int)v.bez, (int)v.dof, (int)v.glass, (int)v.sph, (int)v.stats, v.nt);
+    std::snprintf(name, cap, "trace_grid_%skernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,%sNT=%d>",
+                  (grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER)) ? "sched_" : "", (int)v.trees, (int)v.bez, (int)v.dof,
+                  (int)v.glass, (int)v.sph, (int)v.stats, (grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER)) ? "" : "HPS=0,", v.nt);
     return CGRT_OK;
 }
 
@@ -440,8 +456,9 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.chunk_spp = grid->spp;
     g.partial = nullptr;
     g.partial_nhit = nullptr;
+    g.timeline = nullptr;
     const size_t npx_all = (size_t)grid->rows * grid->width;
-    if (((grid->flags & CGRT_GRID_SPLIT_SAMPLES) || s->dev.has_bezier) && grid->spp >= 32) {
+    if ((grid->flags & CGRT_GRID_SPLIT_SAMPLES) && grid->spp >= 32) {
         int chunks = grid->spp / 16;
         if (chunks > 16) chunks = 16;
         while (chunks > 1 && (size_t)chunks * npx_all * 28 > ((size_t)4 << 30)) chunks--;
@@ -452,9 +469,10 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     }
     // Bezier scenes run one-wave workgroups on 16x4 tiles (TileGeom<64>): waves over the vase outlast their neighbours ~100x
     const bool one_wave = s->dev.has_bezier != 0;
+    const int waves_per_block = one_wave ? 1 : kThreads / 64;
     const int tile_blocks = one_wave ? tile_grid_blocks(g.W, g.rows, false, TileGeom<64>::W, TileGeom<64>::H)
                                      : tile_grid_blocks(g.W, g.rows, g.xcd_tiles != 0);
-    const dim3 grid_dim((unsigned)(tile_blocks * g.chunks)), block(one_wave ? 64 : kThreads);
+    const dim3 natural_dim((unsigned)(tile_blocks * g.chunks)), block(one_wave ? 64 : kThreads);
     size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
@@ -462,63 +480,189 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     ON_DEVICE(s->device);
     const GridVariant gv = grid_variant(s, cam, grid);
     const bool trees = s->dev.has_mesh != 0, dof = gv.dof, bez = gv.bez, glass = gv.glass, stats = gv.stats;
+    // Cost-aware scheduling ("probe -> sort -> plan -> render -> ordered sum").  A frame's cost
+    // is concentrated in a few tiles (a glass mesh: one 32x8 tile ran 38 of the frame's 46 ms while four of the eight XCDs
+    // were idle after 6 ms), the hardware hands out workgroups in block-index order, and a tile is bound to one wave per
+    // 64 pixels.  So: (1) the same kernel traces ONE sample of every wave tile (16x4 pixels) storing nothing but the
+    // shader-clock ticks it took; (2) the wave tiles are sorted by that cost (hipcub radix sort, 4 bytes per wave tile);
+    // (3) plan_kernel marks as HEAVY the tiles that alone would hold a wave slot for more than 1/kHeavyDiv of the frame's
+    // ideal duration; (4) the render launch serves the heavy tiles first, through a queue of (pixel, sample) units that any
+    // lane of any heavy wave may take (GridParams), and renders the rest in image order; (5) deferred_sum_kernel adds the
+    // heavy tiles' Hitpoint values in the reference's order.  The image does not depend on any of this -- every Hitpoint
+    // value is added to its pixel in sample order, emission order within a sample --: identical bits and counters; the probe
+    // costs 1/spp of the frame and the whole scheme is skipped below 4 samples per pixel or on request (CGRT_GRID_NO_REORDER).
+    const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW, wtiles_y = (g.rows + kWaveTileH - 1) / kWaveTileH;
+    const size_t n_wt = (size_t)wtiles_x * wtiles_y;
+    const bool reorder = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && n_wt > 1 && n_wt < (1u << 30);
+    static const long long env_defer_bytes = [] { const char *e = std::getenv("CGRT_DEFER_BYTES"); return e ? std::atoll(e) : 0ll; }();
+    static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
+    static const int env_units = [] { const char *e = std::getenv("CGRT_UNITS_PER_ITEM"); return e ? std::atoi(e) : 0; }();
+    const size_t defer_budget = env_defer_bytes > 0 ? (size_t)env_defer_bytes : ((size_t)4 << 30);  // deferred Hitpoint values, bytes
+    const int heavy_div = env_heavy_div > 0 ? env_heavy_div : 4;
+    const int units_per_item = env_units > 0 ? ((env_units + 63) / 64) * 64 : 256;
+    const int maxhp = glass_possible(s, grid) ? 16 : 1;  // Hitpoints per sample: a mirror chain ends in one, a glass tree of depth 5 in <= 16
+    const size_t tile_vals = (size_t)grid->spp * 64 * (size_t)maxhp * 3 * sizeof(double), tile_cnt = (size_t)grid->spp * 64;
+    const size_t tile_pconst = 7 * 64 * sizeof(double);
+    size_t kmax = 0;
+    const size_t sched_pad = 8;
+    size_t sched_bytes = 0, sort_tmp_bytes = 0, defer_bytes = 0;
+    if (reorder) {
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort_tmp_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_wt, 0, 32, st));
+        sched_bytes = (5 * (n_wt + sched_pad) + 64) * sizeof(uint32_t) + ((sort_tmp_bytes + 255) & ~(size_t)255);
+        sched_bytes = (sched_bytes + 255) & ~(size_t)255;
+        kmax = defer_budget / (tile_vals + tile_cnt + tile_pconst);
+        if (kmax > n_wt) kmax = n_wt;
+        defer_bytes = kmax * (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst) + 256;
+    }
+    size_t chunk_bytes = 0;
+    if (g.chunks > 1) chunk_bytes = (size_t)g.chunks * npx_all * (3 * sizeof(double) + sizeof(uint32_t));
+    const size_t chunk_bytes_al = (chunk_bytes + 255) & ~(size_t)255;
+    const size_t scratch_need = chunk_bytes_al + sched_bytes + defer_bytes;
+    if (scratch_need > 0 && s->scratch_bytes < scratch_need) {
+        if (s->scratch) (void)hipFree(s->scratch);
+        s->scratch = nullptr;
+        s->scratch_bytes = 0;
+        if (hipMalloc(&s->scratch, scratch_need) != hipSuccess)
+            return fail(CGRT_ERR_DEVICE, "cannot allocate launch scratch (chunk sums / schedule / deferred Hitpoint values)");
+        s->scratch_bytes = scratch_need;
+    }
     if (g.chunks > 1) {
-        const size_t need = (size_t)g.chunks * npx_all * (3 * sizeof(double) + sizeof(uint32_t));
-        if (s->scratch_bytes < need) {
-            if (s->scratch) (void)hipFree(s->scratch);
-            s->scratch = nullptr;
-            s->scratch_bytes = 0;
-            if (hipMalloc(&s->scratch, need) != hipSuccess)
-                return fail(CGRT_ERR_DEVICE, "split samples: cannot allocate the chunk sums");
-            s->scratch_bytes = need;
-        }
         g.partial = reinterpret_cast<double *>(s->scratch);
         g.partial_nhit = nhit ? reinterpret_cast<uint32_t *>(g.partial + (size_t)g.chunks * npx_all * 3) : nullptr;
     }
-    if (one_wave) lds += (glass ? TileGeom<64>::stack_bytes : TileGeom<64>::tile_bytes) + sizeof(BezLds);
-    else lds += glass ? kStackBytes : kTileBytes;
+    g.order = nullptr;
+    g.cost = nullptr;
+    g.ids = nullptr;
+    g.hidx = nullptr;
+    g.plan = nullptr;
+    g.dvals = nullptr;
+    g.dcnt = nullptr;
+    g.pconst = nullptr;
+    g.probe = 0;
+    g.heavy_blocks = 0;
+    g.items_per_tile = 1;
+    g.units_per_item = units_per_item;
+    g.maxhp = maxhp;
+    if (one_wave) lds += (glass ? TileGeom<64>::stack_bytes : 0) + sizeof(BezLds);
+    else lds += glass ? kStackBytes : 0;
     if (trees && s->dev.cached_tree >= 0) lds += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
-#define LAUNCH(T, B, D, G, P, S) \
-    hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
+    static const int env_lds_pad = [] { const char *e = std::getenv("CGRT_LDS_PAD"); return e ? std::atoi(e) : 0; }();
+    lds += (size_t)env_lds_pad;
+    auto launch_mode = [&](auto sched_tag, const GridParams &gp, dim3 gd, float *rgb_, uint32_t *nhit_, unsigned long long *cnt_) {
+        constexpr bool SCHED = decltype(sched_tag)::value;
+#define LAUNCH(T, B, D, G, P, S)                                                                                              \
+    do {                                                                                                                      \
+        if (SCHED) hipLaunchKernelGGL((trace_grid_sched_kernel<T, B, D, G, P, S, 256>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); \
+        else hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_);     \
+    } while (0)
 #define LAUNCH_DG(T, B, P, S)                                      \
     do {                                                           \
         if (dof) { if (glass) LAUNCH(T, B, true, true, P, S); else LAUNCH(T, B, true, false, P, S); }   \
         else     { if (glass) LAUNCH(T, B, false, true, P, S); else LAUNCH(T, B, false, false, P, S); } \
     } while (0)
-    if (bez) {  // Bezier scenes share the tree-capable variants (the tree code is skipped when there is no tree)
-#define LAUNCH1(D, G) \
-    hipLaunchKernelGGL((trace_grid_kernel<true, true, D, G, false, false, false, 64>), grid_dim, block, lds, st, s->dev, g, rgb, nhit, cnt)
-        if (dof) { if (glass) LAUNCH1(true, true); else LAUNCH1(true, false); }
-        else     { if (glass) LAUNCH1(false, true); else LAUNCH1(false, false); }
+        if (bez) {  // Bezier scenes share the tree-capable variants (the tree code is skipped when there is no tree)
+#define LAUNCH1(D, G)                                                                                                          \
+    do {                                                                                                                       \
+        if (SCHED) hipLaunchKernelGGL((trace_grid_sched_kernel<true, true, D, G, false, false, 64>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); \
+        else hipLaunchKernelGGL((trace_grid_kernel<true, true, D, G, false, false, false, 64>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_);    \
+    } while (0)
+            if (dof) { if (glass) LAUNCH1(true, true); else LAUNCH1(true, false); }
+            else     { if (glass) LAUNCH1(false, true); else LAUNCH1(false, false); }
 #undef LAUNCH1
-    } else if (trees) {
-        if (stats) LAUNCH_DG(true, false, false, true); else LAUNCH_DG(true, false, false, false);
-    } else if (s->dev.all_spheres) {
-        LAUNCH_DG(false, false, true, false);
-    } else {
-        LAUNCH_DG(false, false, false, false);
-    }
+        } else if (trees) {
+            if (stats) LAUNCH_DG(true, false, false, true); else LAUNCH_DG(true, false, false, false);
+        } else if (s->dev.all_spheres) {
+            LAUNCH_DG(false, false, true, false);
+        } else {
+            LAUNCH_DG(false, false, false, false);
+        }
 #undef LAUNCH_DG
 #undef LAUNCH
+    };
+    auto launch = [&](const GridParams &gp, dim3 gd, float *rgb_, uint32_t *nhit_, unsigned long long *cnt_) {
+        launch_mode(std::false_type{}, gp, gd, rgb_, nhit_, cnt_);
+    };
+    dim3 grid_dim = natural_dim;
+    if (reorder && kmax > 0) {
+        unsigned char *base = reinterpret_cast<unsigned char *>(s->scratch) + chunk_bytes_al;
+        uint32_t *sb = reinterpret_cast<uint32_t *>(base);
+        const size_t np = n_wt + sched_pad;
+        uint32_t *cost = sb, *ids = sb + np, *cost_sorted = sb + 2 * np, *order = sb + 3 * np;
+        int32_t *hidx = reinterpret_cast<int32_t *>(sb + 4 * np);
+        uint32_t *plan = sb + 5 * np;
+        void *sort_tmp = sb + 5 * np + 64;
+        unsigned char *dbase = base + sched_bytes;
+        // wave tiles the probe does not reach (none today) would sort last with cost 0 and their own id
+        HIP_TRY(hipMemsetAsync(cost, 0, np * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ids, 0xff, np * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(hidx, 0xff, np * sizeof(uint32_t), st));
+        GridParams gp = g;  // the probe: this launch's first sample, natural order, one workgroup per tile, nothing stored
+        gp.spp = 1;
+        gp.chunks = 1;
+        gp.chunk_spp = 1;
+        gp.partial = nullptr;
+        gp.partial_nhit = nullptr;
+        gp.probe = 1;
+        gp.cost = cost;
+        gp.ids = ids;
+        gp.timeline = nullptr;
+        launch(gp, dim3((unsigned)tile_blocks), nullptr, nullptr, nullptr);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(sort_tmp, sort_tmp_bytes, cost, cost_sorted, ids, order, (int)n_wt, 0, 32, st));
+        // heavy: cost x spp > (total cost x spp / wave slots) / heavy_div
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
+        const int wave_slots = n_cu * 4 * (one_wave ? 3 : (glass && trees ? 3 : 4));
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, cost_sorted, order, (int)n_wt, (unsigned)kmax,
+                           (unsigned long long)wave_slots * (unsigned long long)heavy_div, plan, hidx);
+        g.order = order;
+        g.hidx = hidx;
+        g.plan = plan;
+        g.dvals = reinterpret_cast<double *>(dbase);
+        g.dcnt = dbase + kmax * tile_vals;
+        g.pconst = reinterpret_cast<double *>(dbase + kmax * (tile_vals + ((tile_cnt + 7) & ~(size_t)7)));
+        g.items_per_tile = (int)(((size_t)grid->spp * 64 + units_per_item - 1) / units_per_item);
+        // enough heavy workgroups to fill the chip once: they loop over the item queue until it is empty
+        size_t hb = (kmax * (size_t)g.items_per_tile + waves_per_block - 1) / waves_per_block;
+        const size_t fill = (size_t)wave_slots / waves_per_block;
+        if (hb > fill) hb = fill;
+        g.heavy_blocks = (int)hb;
+    }
+    // development aid: CGRT_TIMELINE_FILE=path makes this launch synchronous and dumps, per workgroup, when and where it ran
+    DevBuf timeline;
+    const char *timeline_file = std::getenv("CGRT_TIMELINE_FILE");
+    if (timeline_file && *timeline_file) {
+        HIP_TRY(timeline.alloc(((size_t)grid_dim.x + g.heavy_blocks) * 32));
+        HIP_TRY(hipMemsetAsync(timeline.p, 0, ((size_t)grid_dim.x + g.heavy_blocks) * 32, st));
+        g.timeline = timeline.as<unsigned long long>();
+    }
+    if (g.heavy_blocks > 0) {  // heavy workgroups in front, the tile workgroups behind them, one launch
+        hipLaunchKernelGGL(pixel_const_kernel, dim3((unsigned)kmax), dim3(64), 0, st, g);
+        launch_mode(std::true_type{}, g, dim3((unsigned)g.heavy_blocks + grid_dim.x), rgb, nhit, cnt);
+    } else {
+        launch(g, grid_dim, rgb, nhit, cnt);
+    }
     if (g.chunks > 1)
         hipLaunchKernelGGL(finalize_chunks_kernel, dim3((unsigned)((npx_all + 255) / 256)), dim3(256), 0, st, g, rgb, nhit);
+    if (g.heavy_blocks > 0) hipLaunchKernelGGL(deferred_sum_kernel, dim3((unsigned)kmax), dim3(64), 0, st, g, rgb, nhit);
     const hipError_t launch_err = hipGetLastError();
+    if (g.timeline && launch_err == hipSuccess) {
+        std::vector<unsigned long long> tl(((size_t)grid_dim.x + g.heavy_blocks) * 4);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(tl.data(), timeline.p, tl.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(timeline_file, "wb")) {
+            const unsigned long long head[4] = {(unsigned long long)grid_dim.x + g.heavy_blocks, block.x, (unsigned long long)g.chunks, (unsigned long long)g.xcd_tiles};
+            std::fwrite(head, 8, 4, f);
+            std::fwrite(tl.data(), 8, tl.size(), f);
+            std::fclose(f);
+        }
+    }
     if (launch_err != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(launch_err));
     return CGRT_OK;
 }
 
 }  // extern "C"
 
-struct DevBuf {  // RAII for device temporaries: freed on every return path
-    void *p = nullptr;
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    void *release() { void *q = p; p = nullptr; return q; }
-    template <class T> T *as() { return reinterpret_cast<T *>(p); }
-};
 
 // Eye pass with Hitpoint capture into a device buffer of `cap` records (10 doubles each); *count = hitpoints produced.
 // *d_rec_out is hipMalloc'ed here (caller frees) unless cap == 0.
@@ -534,6 +678,9 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     for (int k = 0; k < 3; k++) g.cam[k] = cam->cam[k];
     g.half_width = cam->half_width; g.focus_plane = cam->focus_plane; g.lens_radius = cam->lens_radius;
     g.chunks = 1; g.chunk_spp = grid->spp; g.partial = nullptr; g.partial_nhit = nullptr;  // capture keeps one workgroup per tile
+    g.timeline = nullptr;
+    g.order = nullptr; g.cost = nullptr; g.ids = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
+    g.probe = 0; g.heavy_blocks = 0; g.items_per_tile = 1; g.units_per_item = 256; g.maxhp = 16;
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_rec, b_cnt;
     HIP_TRY(b_rgb.alloc(npx * 3 * sizeof(float)));

@@ -92,14 +92,14 @@ struct LdsAux {
 template <bool STATS>
 __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux &aux, int tr, bool opaque, double bound,
                                             bool on, V3 o, V3 d, V3 inv, uint32_t &n_node, uint32_t &n_tri) {
-    const TreeRec T = sc.trees[tr];
+    const TreeRec T = load_uniform(sc.trees + tr);
     TreeHit none;
     none.len = kInf;
     none.tri = -1;
     none.counter = 0;
     if (!on) return none;
     if (opaque && T.hfield >= 0) {  // bump floor: walk the grid instead of the tree (same triangles, same test)
-        const HFieldRec H = sc.hfields[T.hfield];
+        const HFieldRec H = load_uniform(sc.hfields + T.hfield);
         return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, o, d, inv, bound, n_node, n_tri);
     }
     const bool cached = aux.lnodes != nullptr && tr == sc.cached_tree;
@@ -171,7 +171,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                     const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, fmin(len, best.t), want, o, d, inv, n_node, n_tri);
                     if (want && h.counter > 0 && h.len < len && h.len > 0) {
                         len = h.len;
-                        nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
+                        nrm = tree_normal(sc.tris + load_uniform(&sc.trees[tr].tri_begin), h, d);
                     }
                 }
             }
@@ -188,7 +188,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
                 const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, best.t, on, o, d, inv, n_node, n_tri);
                 if (on && h.counter > 0 && h.len < best.t) {
-                    V3 nrm = tree_normal(sc.tris + sc.trees[tr].tri_begin, h, d);
+                    V3 nrm = tree_normal(sc.tris + load_uniform(&sc.trees[tr].tri_begin), h, d);
                     if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436
                     best.t = h.len;
                     best.id = i;

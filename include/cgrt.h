@@ -74,6 +74,11 @@ enum {
     CGRT_GRID_ACCUMULATE = 2, /* rgb += this pass instead of rgb = this pass: progressive multi-pass rendering with
                                  sample_offset / spp_total, the fp32 replacement for the reference's average.cpp,
                                  which averages nine uint8 images with truncating division (average.cpp:21-64)     */
+    CGRT_GRID_NO_REORDER = 8, /* render the tiles in image order.  By default a launch of >= 4 samples per pixel first traces
+                                 one sample of every 16x4-pixel wave tile to measure its cost, sorts the wave tiles by it and
+                                 renders heaviest first, which keeps all eight XCDs busy when a few tiles carry the work;
+                                 the image, hit counts and counters are identical either way (this flag exists to measure
+                                 the difference and to test both paths)                                              */
     CGRT_GRID_SPLIT_SAMPLES = 4 /* let several workgroups share a tile's samples: each sums a contiguous chunk of the
                                  samples in fp64 and the chunk sums are added in chunk order by a second kernel.
                                  Reproducible, but the fp64 summation ORDER differs from the sample-by-sample sum

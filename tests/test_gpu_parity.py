@@ -526,3 +526,30 @@ def test_split_samples_mode(gpu_ready, orc):
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy() - plain["rgb"]).max() <= 1e-6
     sc.close()
+
+
+@pytest.mark.parametrize("name,mk,cam,W,H,spp", [
+    ("c2", scenes.scene_c2, scenes.cam_dof, 333, 187, 8),
+    ("bunny_glass", lambda: scenes.scene_c3(True), scenes.cam_dof, 256, 200, 6),
+    ("dragon", scenes.scene_dragon, scenes.cam_pinhole, 200, 160, 4),
+    ("vase", lambda: scenes.scene_c5(scenes.stone_small_texture(True)), scenes.cam_dof, 128, 96, 4),
+])
+def test_cost_ordered_schedule_changes_nothing(gpu_ready, name, mk, cam, W, H, spp):
+    """Probe -> sort -> render (the default for >= 4 samples per pixel: wave tiles rendered heaviest first) against
+    CGRT_GRID_NO_REORDER (image order): identical image bits, per-pixel hitpoint counts and counters -- the probe's rays
+    are not counted twice --, also in stripes, with a sample offset, with accumulation and with split samples."""
+    import cgraytracing_amd as cg
+    with cg.Scene(mk()) as sc:
+        a = sc.trace_grid_host(W, H, spp, cam(), 5, 77)
+        b = sc.trace_grid_host(W, H, spp, cam(), 5, 77, reorder=False)
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["nhit"], b["nhit"])
+        assert np.array_equal(a["counters"][:2], b["counters"][:2]) and a["nrays"] >= W * H * spp
+        # stripes of rank 1 of 3, second half of the samples
+        kw = dict(rows=64, stripe=(8, 1, 3), sample_offset=spp // 2, spp_total=spp)
+        c = sc.trace_grid_host(W, H, spp - spp // 2, cam(), 5, 77, **kw)
+        d = sc.trace_grid_host(W, H, spp - spp // 2, cam(), 5, 77, reorder=False, **kw)
+        assert np.array_equal(c["rgb"], d["rgb"]) and np.array_equal(c["counters"][:2], d["counters"][:2])
+        if name != "vase":  # Bezier scenes always split samples
+            e = sc.trace_grid_host(W, H, 64, cam(), 5, 77, split_samples=True)
+            f = sc.trace_grid_host(W, H, 64, cam(), 5, 77, split_samples=True, reorder=False)
+            assert np.array_equal(e["rgb"], f["rgb"]) and np.array_equal(e["counters"][:2], f["counters"][:2])

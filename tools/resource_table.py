@@ -16,6 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def demangle_variant(name):
+    m = re.match(r"_Z17trace_grid_kernelIL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)ELi(\d+)EL?b(\d)EE", name)
+    if m:
+        t = [int(x) for x in m.groups()]
+        return "trace_grid_kernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,HPS=%d,NT=%d,HEAVY=%d>" % tuple(t)
+    m = re.match(r"_Z23trace_grid_sched_kernelIL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)ELi(\d+)EE", name)
+    if m:
+        t = [int(x) for x in m.groups()]
+        return "trace_grid_sched_kernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,NT=%d>" % tuple(t)
     m = re.match(r"_Z17trace_grid_kernelIL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)ELi(\d+)EE", name)
     if m:
         t = [int(x) for x in m.groups()]
