@@ -16,6 +16,11 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
 // pending-ray storage (LDS levels, sibling registers) is compiled out and occupancy goes up.
 // SPH: every object is a sphere (C1/C2-type scenes): specialised object loop.
 // HPS: additionally append every Hitpoint {f, pos, normal} (hitpoints.h:6-20, main.cpp:87-98) to a global stream.
+#ifndef CGRT_BEZ_WAVES
+#define CGRT_BEZ_WAVES 3
+#endif
+static constexpr int kBezWaves = CGRT_BEZ_WAVES;  // waves per SIMD the Bezier variants are compiled for
+
 struct HitpointSink {
     double *rec;                // cap x 10 doubles: f(3) pos(3) normal(3) label
     unsigned long long *count;  // appended so far (may exceed cap: then the tail was dropped)
@@ -377,7 +382,6 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
             const long long dt = (long long)clock64() - cost_t0;
             const uint32_t wt = (uint32_t)(wy * wtiles_x + wx);
             g.cost[wt] = dt > 0 ? (dt < 0xffffffffll ? (uint32_t)dt : 0xffffffffu) : 1u;
-            g.ids[wt] = wt;
         }
         return;  // no counters: the render launch that follows counts these rays
     }
@@ -454,7 +458,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
 
 // One launch = tile workgroups only (probe, image order, Hitpoint capture) ...
 template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256>
-__global__ __launch_bounds__(NT, BEZ ? 3 : (TREES ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+__global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters,
                                                              HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(NT, BEZ ? 3 : (TREES ? 3 : 4)) void trace_grid_kern
 // tile workgroups take over the slots as the heavy waves retire -- no seam between two launches.  Each body keeps its own
 // register allocation (the paths are disjoint); the kernel's register and scratch sizes are the larger of the two.
 template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, int NT = 256>
-__global__ __launch_bounds__(NT, BEZ ? 3 : (TREES ? 3 : 4)) void trace_grid_sched_kernel(DeviceScene sc, GridParams g,
+__global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? 3 : 4)) void trace_grid_sched_kernel(DeviceScene sc, GridParams g,
                                                                                          float *__restrict__ rgb,
                                                                                          uint32_t *__restrict__ nhit_out,
                                                                                          unsigned long long *__restrict__ counters) {
@@ -508,17 +512,26 @@ __global__ void finalize_chunks_kernel(GridParams g, float *__restrict__ rgb, ui
 }
 
 // ---- cost-aware scheduling: plan and ordered sum (GridParams, "Cost-aware scheduling") ------------------------------------
-// One workgroup.  cost_sorted: the wave tiles' probe costs, descending; order: their numbers.  A wave tile is HEAVY when its
-// cost exceeds total / divisor -- divisor = wave slots of the chip x a constant, i.e. when the tile alone would occupy a wave
-// slot for more than 1/constant of the frame's ideal duration -- at most kmax of them (what the deferred buffers hold).
-// plan[0] = K, plan[1] = threshold, plan[2] = 0 (the item queue's head); hidx[wave tile] = rank for the K heavy ones.
-__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ cost_sorted, const uint32_t *__restrict__ order,
-                                                    int n, unsigned kmax, unsigned long long divisor, uint32_t *__restrict__ plan,
-                                                    int32_t *__restrict__ hidx) {
+// One workgroup.  cost[]: the wave tiles' probe costs.  A wave tile is HEAVY when its cost exceeds total / divisor --
+// divisor = wave slots of the chip x a constant, i.e. when the tile alone would occupy a wave slot for more than 1/constant
+// of the frame's ideal duration.  At most kmax tiles can be heavy (what the deferred buffers hold): if more exceed the
+// threshold it is raised, on a quarter-octave histogram of the costs, until the count fits -- the heaviest stay.
+// Output: order[0..K) = the heavy wave tiles, heaviest histogram bin first, hidx[wave tile] = rank or -1, plan[0] = K,
+// plan[1] = threshold, plan[2] = 0 (the item queue's head).
+__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ cost, int n, unsigned kmax, unsigned long long divisor,
+                                                    uint32_t *__restrict__ plan, uint32_t *__restrict__ order, int32_t *__restrict__ hidx) {
     __shared__ unsigned long long part[1024];
-    __shared__ unsigned k_heavy;
+    __shared__ unsigned base_s, hist[128];
+    __shared__ unsigned long long thr_s;
+    auto bin_of = [](uint32_t c) { return c < 4u ? (int)c : (31 - __clz((int)c)) * 4 + (int)((c >> (29 - __clz((int)c))) & 3u); };
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    __syncthreads();
     unsigned long long t = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) t += cost_sorted[i];
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t c = cost[i];
+        t += c;
+        atomicAdd(&hist[bin_of(c)], 1u);
+    }
     part[threadIdx.x] = t;
     __syncthreads();
     for (int off = 512; off > 0; off >>= 1) {
@@ -528,20 +541,60 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
     if (threadIdx.x == 0) {
         unsigned long long thr = part[0] / divisor;
         if (thr < 1) thr = 1;
-        int lo = 0, hi = n;  // first index whose cost is <= thr (the list is descending)
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((unsigned long long)cost_sorted[mid] > thr) lo = mid + 1; else hi = mid;
+        // raise the threshold to the lower edge of the lowest histogram bin such that all bins above it hold <= kmax tiles
+        unsigned above = 0;
+        int b = 127;
+        for (; b >= 0; b--) {
+            if (above + hist[b] > kmax) break;
+            above += hist[b];
         }
-        unsigned k = (unsigned)lo;
-        if (k > kmax) k = kmax;
-        k_heavy = k;
-        plan[0] = k;
+        if (b >= 0) {  // bins 0..b must stay out: threshold = the largest cost of bin b
+            const unsigned long long edge = b < 4 ? (unsigned long long)b
+                                                  : (((4ull + (unsigned long long)(b & 3) + 1ull) << (b / 4)) >> 2) - 1ull;
+            if (edge > thr) thr = edge;
+        }
+        thr_s = thr;
+        base_s = 0;
+    }
+    __syncthreads();
+    const unsigned long long thr = thr_s;
+    // Counting sort of the heavy tiles by histogram bin, heaviest bin first (longest-processing-time-first at quarter-octave
+    // resolution; the order inside a bin is whatever the atomics give -- it affects neither the image nor the counters).
+    // hist[] is reused: bins wholly above the threshold get their start offset, the others nothing.
+    if (threadIdx.x == 0) {
+        unsigned off = 0;
+        for (int b = 127; b >= 0; b--) {
+            const unsigned long long lo = b < 4 ? (unsigned long long)b : ((4ull + (unsigned long long)(b & 3)) << (b / 4)) >> 2;  // smallest cost of bin b
+            const unsigned c = hist[b];
+            if (lo > thr) {
+                hist[b] = off;
+                off += c;
+            } else {
+                hist[b] = 0xffffffffu;  // the bin holding the threshold (its costs may lie on either side) and all below: not heavy
+            }
+        }
+        base_s = off < kmax ? off : kmax;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t c = cost[i];
+        const int b = bin_of(c);
+        int32_t r = -1;
+        if (hist[b] != 0xffffffffu) {
+            const unsigned slot = atomicAdd(&hist[b], 1u);
+            if (slot < kmax) {
+                r = (int32_t)slot;
+                order[slot] = (uint32_t)i;
+            }
+        }
+        hidx[i] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        plan[0] = base_s;
         plan[1] = (uint32_t)(thr > 0xffffffffull ? 0xffffffffull : thr);
         plan[2] = 0;
     }
-    __syncthreads();
-    for (unsigned i = threadIdx.x; i < k_heavy; i += 1024) hidx[order[i]] = (int32_t)i;
 }
 
 // The per-pixel camera constants of the heavy tiles (what set_pixel computes), one 64-thread workgroup per heavy tile.

@@ -19,9 +19,8 @@ struct GridParams {
     // Cost-aware scheduling (cgrt_hip.hip, "probe -> sort -> plan -> render -> ordered sum").  The unit of
     // bookkeeping is a WAVE TILE of 16x4 pixels, numbered wy * ceil(W/16) + wx over the local rows.
     //   probe != 0 : trace this launch's first sample only to measure it -- nothing is stored except cost[wave tile] =
-    //                shader-clock ticks the wave spent on it and ids[wave tile] = wave tile (the sort's payload).
-    //   render     : order[] = wave tiles by descending cost, plan[0] = K = how many of them are HEAVY, hidx[wave tile] =
-    //                rank among the heavy ones or -1.  A first launch (the HEAVY kernel variant, heavy_blocks workgroups that
+    //                shader-clock ticks the wave spent on it.
+    //   render     : order[0..K) = the HEAVY wave tiles (plan_kernel), plan[0] = K, hidx[wave tile] = rank among them or -1.  A first launch (the HEAVY kernel variant, heavy_blocks workgroups that
     //                loop until the queue is empty) serves the heavy tiles through a queue of ITEMS (plan[2] = next item; item = heavy tile rank * items_per_tile + part): an item is
     //                units_per_item (pixel, sample) UNITS of one heavy tile, which the lanes of the wave take one after
     //                another as they become free, so a heavy tile is spread over many waves on many CUs and no lane idles
@@ -30,7 +29,7 @@ struct GridParams {
     //                sample, emission order within a sample -- so the fp64 sum is bit for bit the sequential one.  The
     //                tile launch renders the other tiles in image order (waves whose tile is heavy stand down).
     const uint32_t *order;
-    uint32_t *cost, *ids;
+    uint32_t *cost;
     const int32_t *hidx;
     uint32_t *plan;
     double *dvals;

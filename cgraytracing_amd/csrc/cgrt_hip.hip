@@ -12,7 +12,6 @@
 //     to fp32 and written through an LDS transpose as 384-byte contiguous row segments.
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -498,20 +497,18 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
     static const int env_units = [] { const char *e = std::getenv("CGRT_UNITS_PER_ITEM"); return e ? std::atoi(e) : 0; }();
     const size_t defer_budget = env_defer_bytes > 0 ? (size_t)env_defer_bytes : ((size_t)4 << 30);  // deferred Hitpoint values, bytes
-    const int heavy_div = env_heavy_div > 0 ? env_heavy_div : 4;
+    const int heavy_div = env_heavy_div > 0 ? env_heavy_div : 32;
     const int units_per_item = env_units > 0 ? ((env_units + 63) / 64) * 64 : 256;
     const int maxhp = glass_possible(s, grid) ? 16 : 1;  // Hitpoints per sample: a mirror chain ends in one, a glass tree of depth 5 in <= 16
     const size_t tile_vals = (size_t)grid->spp * 64 * (size_t)maxhp * 3 * sizeof(double), tile_cnt = (size_t)grid->spp * 64;
     const size_t tile_pconst = 7 * 64 * sizeof(double);
     size_t kmax = 0;
     const size_t sched_pad = 8;
-    size_t sched_bytes = 0, sort_tmp_bytes = 0, defer_bytes = 0;
+    size_t sched_bytes = 0, defer_bytes = 0;
     if (reorder) {
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort_tmp_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_wt, 0, 32, st));
-        sched_bytes = (5 * (n_wt + sched_pad) + 64) * sizeof(uint32_t) + ((sort_tmp_bytes + 255) & ~(size_t)255);
+        sched_bytes = (3 * (n_wt + sched_pad) + 64) * sizeof(uint32_t);
         sched_bytes = (sched_bytes + 255) & ~(size_t)255;
-        kmax = defer_budget / (tile_vals + tile_cnt + tile_pconst);
+        kmax = defer_budget / (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst);
         if (kmax > n_wt) kmax = n_wt;
         defer_bytes = kmax * (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst) + 256;
     }
@@ -533,7 +530,6 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     }
     g.order = nullptr;
     g.cost = nullptr;
-    g.ids = nullptr;
     g.hidx = nullptr;
     g.plan = nullptr;
     g.dvals = nullptr;
@@ -588,15 +584,10 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         unsigned char *base = reinterpret_cast<unsigned char *>(s->scratch) + chunk_bytes_al;
         uint32_t *sb = reinterpret_cast<uint32_t *>(base);
         const size_t np = n_wt + sched_pad;
-        uint32_t *cost = sb, *ids = sb + np, *cost_sorted = sb + 2 * np, *order = sb + 3 * np;
-        int32_t *hidx = reinterpret_cast<int32_t *>(sb + 4 * np);
-        uint32_t *plan = sb + 5 * np;
-        void *sort_tmp = sb + 5 * np + 64;
+        uint32_t *cost = sb, *order = sb + np;
+        int32_t *hidx = reinterpret_cast<int32_t *>(sb + 2 * np);
+        uint32_t *plan = sb + 3 * np;
         unsigned char *dbase = base + sched_bytes;
-        // wave tiles the probe does not reach (none today) would sort last with cost 0 and their own id
-        HIP_TRY(hipMemsetAsync(cost, 0, np * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(ids, 0xff, np * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(hidx, 0xff, np * sizeof(uint32_t), st));
         GridParams gp = g;  // the probe: this launch's first sample, natural order, one workgroup per tile, nothing stored
         gp.spp = 1;
         gp.chunks = 1;
@@ -605,16 +596,14 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         gp.partial_nhit = nullptr;
         gp.probe = 1;
         gp.cost = cost;
-        gp.ids = ids;
         gp.timeline = nullptr;
         launch(gp, dim3((unsigned)tile_blocks), nullptr, nullptr, nullptr);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(sort_tmp, sort_tmp_bytes, cost, cost_sorted, ids, order, (int)n_wt, 0, 32, st));
         // heavy: cost x spp > (total cost x spp / wave slots) / heavy_div
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
-        const int wave_slots = n_cu * 4 * (one_wave ? 3 : (glass && trees ? 3 : 4));
-        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, cost_sorted, order, (int)n_wt, (unsigned)kmax,
-                           (unsigned long long)wave_slots * (unsigned long long)heavy_div, plan, hidx);
+        const int wave_slots = n_cu * 4 * (one_wave ? kBezWaves : (trees ? 3 : 4));
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, cost, (int)n_wt, (unsigned)kmax,
+                           (unsigned long long)wave_slots * (unsigned long long)heavy_div, plan, order, hidx);
         g.order = order;
         g.hidx = hidx;
         g.plan = plan;
@@ -679,7 +668,7 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     g.half_width = cam->half_width; g.focus_plane = cam->focus_plane; g.lens_radius = cam->lens_radius;
     g.chunks = 1; g.chunk_spp = grid->spp; g.partial = nullptr; g.partial_nhit = nullptr;  // capture keeps one workgroup per tile
     g.timeline = nullptr;
-    g.order = nullptr; g.cost = nullptr; g.ids = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
+    g.order = nullptr; g.cost = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
     g.probe = 0; g.heavy_blocks = 0; g.items_per_tile = 1; g.units_per_item = 256; g.maxhp = 16;
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_rec, b_cnt;
