@@ -607,6 +607,22 @@ int HostScene::add_mesh_triangles(const double *tri9, int ntri, const double sc[
     HostTree tree;
     tree.tri9.assign(tri9, tri9 + (size_t)ntri * 9);
     tree.build(transp < kEps);  // objects.h:402; an opaque owner gets the triangle-level hierarchy
+    {   // bounding sphere of the mesh (a = centre, s0 = radius^2): the scene walk's division-free early-out.  It contains the
+        // root box grown by more than the box test's 1e-4 slack, so a ray that misses it cannot touch any node.
+        double lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+        for (size_t i = 0; i < tree.tri9.size(); i++) {
+            lo[i % 3] = std::min(lo[i % 3], tree.tri9[i]);
+            hi[i % 3] = std::max(hi[i % 3], tree.tri9[i]);
+        }
+        double r2 = 0;
+        for (int k = 0; k < 3; k++) {
+            if (ntri == 0) { lo[k] = hi[k] = 0; }
+            o.a[k] = 0.5 * (lo[k] + hi[k]);
+            const double h = 0.5 * (hi[k] - lo[k]) + 1e-3;
+            r2 += h * h;
+        }
+        o.s0 = ntri == 0 ? -1.0 : r2 * (1 + 1e-9);  // empty mesh: nothing to hit
+    }
     trees.push_back(std::move(tree));
     o.tree = (int)trees.size() - 1;
     objs.push_back(o);

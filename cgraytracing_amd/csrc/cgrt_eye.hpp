@@ -103,8 +103,10 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
         wx = tile_x * (TG::W / kWaveTileW) + (NT == 256 ? (wave & 1) : 0);
         wy = tile_y * (TG::H / kWaveTileH) + (NT == 256 ? (wave >> 1) : 0);
         have_tile = wx < wtiles_x && wy < wtiles_y;
-        // a heavy tile is rendered by the heavy workgroups: its wave stands down here
+        // a heavy tile is rendered by the heavy workgroups: its wave stands down here; so does the wave of a tile that
+        // belongs to the other launch of a light / full pair (the probe measures every tile)
         if (have_tile && g.hidx && g.hidx[wy * wtiles_x + wx] >= 0) have_tile = false;
+        if (have_tile && g.light && !g.probe && (g.light[wy * wtiles_x + wx] != 0) != (g.light_mode != 0)) have_tile = false;
         s_end = (g.chunks > 1) ? ((chunk + 1) * g.chunk_spp < g.spp ? (chunk + 1) * g.chunk_spp : g.spp) : g.spp;
         set_pixel(lane & 15, lane >> 4);
     }
@@ -444,7 +446,9 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                 tt += __shfl_xor(tt, off);
             }
         }
-        if (lane == 0) {
+        // a wave that traced nothing (its tile belongs to another launch, or lies outside the image) adds nothing: same-address
+        // atomics serialise in L2 at ~16 ns each, which 260 000 idle waves would turn into milliseconds
+        if (lane == 0 && (r | (unsigned long long)wave_iters) != 0ull) {
             atomicAdd(&counters[CGRT_CNT_RAYS], r);
             atomicAdd(&counters[CGRT_CNT_HITPOINTS], hh);
             atomicAdd(&counters[CGRT_CNT_WAVE_ITERS], (unsigned long long)wave_iters);
@@ -511,6 +515,75 @@ __global__ void finalize_chunks_kernel(GridParams g, float *__restrict__ rgb, ui
     if (nhit_out) nhit_out[px] = hits;
 }
 
+// ---- light tiles -------------------------------------------------------------------------------------------------------
+// One thread per wave tile (16x4 pixels).  The tile is LIGHT when no primary ray of it -- any pixel, any lens sample -- can
+// touch the bounding sphere of a "special" object: a mesh or Bezier object (trees, Newton) or a sphere that reflects or
+// refracts (secondary rays go anywhere).  With every plane diffuse and un-bumped (DeviceScene::light_ok) such a tile's rays
+// end on a diffuse sphere or plane after one scene walk, whatever the sample: the variant without tree / Bezier / pending-ray
+// code renders it exactly.  Conservative bound: the tile's pinhole directions lie in a cone around its centre direction
+// (half-angle = 1.5 x the largest corner deviation + 1e-6); a thin-lens ray deviates from its pinhole ray, at depth z, by
+// lens_radius * |1 - (z - cam.z) / (focus_plane - cam.z)| sideways, so the object's sphere is grown by the largest such
+// deviation over its depth range.  Anything doubtful (object behind or around the camera, rows beyond the image) is FULL.
+__global__ void classify_kernel(DeviceScene sc, GridParams g, unsigned char *__restrict__ light, int n_wt) {
+    const int wt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wt >= n_wt) return;
+    const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW;
+    const int wx = wt % wtiles_x, wy = wt / wtiles_x;
+    const V3 cam = mk(g.cam[0], g.cam[1], g.cam[2]);
+    auto dir_of = [&](int w, int j) {
+        const int h = global_row(g, j);
+        const double px = (2.0 * ((double)w / g.W) - 1) * g.half_width;
+        const double py = (2.0 * ((double)h / g.H) - 1) * g.half_width * g.H / g.W;
+        return normalized(mk(px, py, 0) - cam);
+    };
+    const int w0 = wx * kWaveTileW, j0 = wy * kWaveTileH;
+    // corners one pixel beyond the tile on every side (pixels are sampled at their lower-left corner; the margin also covers
+    // the curvature of the angle function along the edges)
+    const V3 c00 = dir_of(w0 - 1, j0 - 1), c10 = dir_of(w0 + kWaveTileW, j0 - 1), c01 = dir_of(w0 - 1, j0 + kWaveTileH),
+             c11 = dir_of(w0 + kWaveTileW, j0 + kWaveTileH);
+    const V3 dc = normalized((c00 + c10) + (c01 + c11));
+    double cmin = fmin(fmin(dot(dc, c00), dot(dc, c10)), fmin(dot(dc, c01), dot(dc, c11)));
+    cmin = fmin(1.0, fmax(-1.0, cmin));
+    const double alpha = 1.5 * acos(cmin) + 1e-6;
+    bool is_light = true;
+    // the stripe mapping keeps a wave tile's four rows adjacent (stripes are multiples of 8 rows), so the corners bound it
+    for (int i = 0; i < sc.n_objs && is_light; i++) {
+        const ObjRec &ob = sc.objs[i];
+        V3 c;
+        double r;
+        if (ob.kind == KIND_SPHERE) {
+            if (ob.refl < kEps && ob.transp < kEps) continue;  // diffuse: no secondary rays
+            c = ld3(ob.a);
+            r = sqrt(ob.s0);
+        } else if (ob.kind == KIND_MESH) {
+            if (ob.s0 < 0) continue;  // empty mesh
+            c = ld3(ob.a);
+            r = sqrt(ob.s0);
+        } else if (ob.kind == KIND_BEZIER) {
+            const BezierRec &bz = sc.beziers[ob.aux];
+            c = mk(0.5 * (bz.box[0] + bz.box[1]), 0.5 * (bz.box[2] + bz.box[3]), 0.5 * (bz.box[4] + bz.box[5]));
+            const V3 hw = mk(0.5 * (bz.box[1] - bz.box[0]), 0.5 * (bz.box[3] - bz.box[2]), 0.5 * (bz.box[5] - bz.box[4]));
+            r = sqrt(dot(hw, hw)) + 1e-3;
+        } else {
+            continue;  // planes: vetted by light_ok
+        }
+        r = r * (1 + 1e-9) + 1e-6;
+        if (g.lens_radius > 0) {
+            const double f = g.focus_plane - cam.z;
+            const double s_lo = (c.z - r - cam.z) / f, s_hi = (c.z + r - cam.z) / f;
+            if (!(f > 0) || !(s_lo > 0)) { is_light = false; break; }  // object reaches the lens plane or behind it
+            r += g.lens_radius * fmax(fabs(1 - s_lo), fabs(1 - s_hi));
+        }
+        const V3 v = c - cam;
+        const double dist = sqrt(dot(v, v));
+        if (!(dist > r)) { is_light = false; break; }
+        double ct = dot(dc, v) / dist;
+        ct = fmin(1.0, fmax(-1.0, ct));
+        if (acos(ct) <= alpha + asin(r / dist) + 1e-6) is_light = false;
+    }
+    light[wt] = is_light ? 1 : 0;
+}
+
 // ---- cost-aware scheduling: plan and ordered sum (GridParams, "Cost-aware scheduling") ------------------------------------
 // One workgroup.  cost[]: the wave tiles' probe costs.  A wave tile is HEAVY when its cost exceeds total / divisor --
 // divisor = wave slots of the chip x a constant, i.e. when the tile alone would occupy a wave slot for more than 1/constant
@@ -518,8 +591,11 @@ __global__ void finalize_chunks_kernel(GridParams g, float *__restrict__ rgb, ui
 // threshold it is raised, on a quarter-octave histogram of the costs, until the count fits -- the heaviest stay.
 // Output: order[0..K) = the heavy wave tiles, heaviest histogram bin first, hidx[wave tile] = rank or -1, plan[0] = K,
 // plan[1] = threshold, plan[2] = 0 (the item queue's head).
-__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ cost, int n, unsigned kmax, unsigned long long divisor,
-                                                    uint32_t *__restrict__ plan, uint32_t *__restrict__ order, int32_t *__restrict__ hidx) {
+__global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ cost_in, const unsigned char *__restrict__ light, int n,
+                                                    unsigned kmax, unsigned long long divisor, uint32_t *__restrict__ plan,
+                                                    uint32_t *__restrict__ order, int32_t *__restrict__ hidx) {
+    // a light tile (rendered by the other launch) counts for nothing here
+    auto cost = [&](int i) -> uint32_t { return (light && light[i]) ? 0u : cost_in[i]; };
     __shared__ unsigned long long part[1024];
     __shared__ unsigned base_s, hist[128];
     __shared__ unsigned long long thr_s;
@@ -528,7 +604,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
     __syncthreads();
     unsigned long long t = 0;
     for (int i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t c = cost[i];
+        const uint32_t c = cost(i);
         t += c;
         atomicAdd(&hist[bin_of(c)], 1u);
     }
@@ -577,7 +653,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t c = cost[i];
+        const uint32_t c = cost(i);
         const int b = bin_of(c);
         int32_t r = -1;
         if (hist[b] != 0xffffffffu) {

@@ -28,6 +28,12 @@ struct GridParams {
     //                (dcnt = how many), and deferred_sum_kernel adds them per pixel in the reference's order -- sample by
     //                sample, emission order within a sample -- so the fp64 sum is bit for bit the sequential one.  The
     //                tile launch renders the other tiles in image order (waves whose tile is heavy stand down).
+    // Light tiles (classify_kernel): light[wave tile] != 0 -- no primary ray of the tile can come near a mesh, a Bezier
+    // object or a mirror / glass sphere, so it is rendered by the kernel variant without tree, Bezier and pending-ray code
+    // (fewer registers, more waves per SIMD), launched beside the full variant on a second stream.  light_mode: 0 = this
+    // launch leaves the light tiles alone, 1 = this launch renders only them; light == nullptr: no split.
+    const unsigned char *light;
+    int32_t light_mode, pad_light_;
     const uint32_t *order;
     uint32_t *cost;
     const int32_t *hidx;

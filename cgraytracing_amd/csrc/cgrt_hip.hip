@@ -52,6 +52,9 @@ struct cgrt_scene {
     // (launches on one handle are ordered by the caller: cgrt.h, "Threading")
     mutable void *scratch = nullptr;
     mutable size_t scratch_bytes = 0;
+    // second stream + fork/join events for the light-tile launch that runs beside the full one (created at commit)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static thread_local std::string g_err;
@@ -127,11 +130,14 @@ int cgrt_scene_create(cgrt_scene **out) {
 
 void cgrt_scene_destroy(cgrt_scene *s) {
     if (!s) return;
-    if (!s->allocs.empty() || s->scratch) {
+    if (!s->allocs.empty() || s->scratch || s->aux_stream) {
         DeviceGuard g(s->device);
         if (g.err == hipSuccess) {
             for (void *p : s->allocs) (void)hipFree(p);
             if (s->scratch) (void)hipFree(s->scratch);
+            if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+            if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+            if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
         }
     }
     delete s;
@@ -300,6 +306,23 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         if (o.kind != KIND_SPHERE) d.all_spheres = 0;
         if (!(o.transp < kEps)) d.has_glass = 1;  // main.cpp:129: the glass branch is `!(transparency < eps)`
     }
+    // light tiles (classify_kernel): possible when planes are plain diffuse surfaces and something else is not
+    {
+        bool planes_plain = true, special = false;
+        for (auto &o : H.objs) {
+            const bool diffuse = o.refl < kEps && o.transp < kEps;
+            if (o.kind == KIND_PLANE && (!diffuse || o.tree >= 0)) planes_plain = false;
+            if (o.kind == KIND_MESH || o.kind == KIND_BEZIER || (o.kind == KIND_SPHERE && !diffuse)) special = true;
+        }
+        d.light_ok = (planes_plain && special && !d.all_spheres) ? 1 : 0;
+        d.pad_ = 0;
+        if (d.light_ok && !s->aux_stream) {
+            if (hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
+                d.light_ok = 0;  // no second stream: render everything with the full variant
+        }
+    }
     s->dev = d;
     s->committed = true;
     return CGRT_OK;
@@ -379,6 +402,7 @@ int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int3
 // Which instantiation of trace_grid_kernel a launch uses (chosen from the scene's materials and the camera).
 struct GridVariant {
     bool trees, bez, dof, glass, sph, stats;
+    bool sched;  // the scheduled form (trace_grid_sched_kernel): heavy-tile unit queue in front of the tile workgroups
     int nt;  // threads per workgroup: 256 (32x8-pixel tiles) or 64 (Bezier scenes: one-wave workgroups on 16x4 tiles)
 };
 static GridVariant grid_variant(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid) {
@@ -390,6 +414,8 @@ static GridVariant grid_variant(const cgrt_scene *s, const cgrt_camera *cam, con
     v.sph = !v.trees && s->dev.all_spheres != 0;
     v.stats = (grid->flags & CGRT_GRID_STATS) != 0 && s->dev.has_mesh != 0 && !v.bez;
     v.nt = v.bez ? 64 : kThreads;
+    v.sched = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER)) &&
+              ((size_t)((grid->width + kWaveTileW - 1) / kWaveTileW) * ((grid->rows + kWaveTileH - 1) / kWaveTileH)) > 1;
     return v;
 }
 
@@ -418,8 +444,8 @@ int cgrt_trace_grid_variant(const cgrt_scene *s, const cgrt_camera *cam, const c
     if (!name || cap == 0) return fail(CGRT_ERR_INVALID, "null name buffer");
     const GridVariant v = grid_variant(s, cam, grid);
     std::snprintf(name, cap, "trace_grid_%skernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,%sNT=%d>",
-                  (grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER)) ? "sched_" : "", (int)v.trees, (int)v.bez, (int)v.dof,
-                  (int)v.glass, (int)v.sph, (int)v.stats, (grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER)) ? "" : "HPS=0,", v.nt);
+                  v.sched ? "sched_" : "", (int)v.trees, (int)v.bez, (int)v.dof, (int)v.glass, (int)v.sph, (int)v.stats,
+                  v.sched ? "" : "HPS=0,", v.nt);
     return CGRT_OK;
 }
 
@@ -492,7 +518,12 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     // costs 1/spp of the frame and the whole scheme is skipped below 4 samples per pixel or on request (CGRT_GRID_NO_REORDER).
     const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW, wtiles_y = (g.rows + kWaveTileH - 1) / kWaveTileH;
     const size_t n_wt = (size_t)wtiles_x * wtiles_y;
-    const bool reorder = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && n_wt > 1 && n_wt < (1u << 30);
+    // Sphere-only scenes are left in image order: without a tree or a Newton solve behind a ray, a tile's cost varies only
+    // with the size of its ray trees (<= 31 rays per sample), the per-lane sample loop already keeps 97 % of the lanes busy,
+    // and measured on C2 the unit queue costs 13 % more VALU instructions (at 93 % VALU busy) and 0.9 GB of deferred values
+    // per frame for a gain within the noise (4.0-4.2 ms either way).
+    const bool reorder = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && n_wt > 1 && n_wt < (1u << 30) &&
+                         (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER));
     static const long long env_defer_bytes = [] { const char *e = std::getenv("CGRT_DEFER_BYTES"); return e ? std::atoll(e) : 0ll; }();
     static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
     static const int env_units = [] { const char *e = std::getenv("CGRT_UNITS_PER_ITEM"); return e ? std::atoi(e) : 0; }();
@@ -506,7 +537,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const size_t sched_pad = 8;
     size_t sched_bytes = 0, defer_bytes = 0;
     if (reorder) {
-        sched_bytes = (3 * (n_wt + sched_pad) + 64) * sizeof(uint32_t);
+        sched_bytes = (3 * (n_wt + sched_pad) + 64) * sizeof(uint32_t) + ((n_wt + 255) & ~(size_t)255);  // cost, order, hidx, plan, light
         sched_bytes = (sched_bytes + 255) & ~(size_t)255;
         kmax = defer_budget / (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst);
         if (kmax > n_wt) kmax = n_wt;
@@ -528,6 +559,9 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         g.partial = reinterpret_cast<double *>(s->scratch);
         g.partial_nhit = nhit ? reinterpret_cast<uint32_t *>(g.partial + (size_t)g.chunks * npx_all * 3) : nullptr;
     }
+    g.light = nullptr;
+    g.light_mode = 0;
+    g.pad_light_ = 0;
     g.order = nullptr;
     g.cost = nullptr;
     g.hidx = nullptr;
@@ -587,7 +621,11 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         uint32_t *cost = sb, *order = sb + np;
         int32_t *hidx = reinterpret_cast<int32_t *>(sb + 2 * np);
         uint32_t *plan = sb + 3 * np;
+        unsigned char *light = reinterpret_cast<unsigned char *>(sb + 3 * np + 64);
         unsigned char *dbase = base + sched_bytes;
+        const bool split_light = s->dev.light_ok != 0 && g.chunks == 1 && !stats;
+        if (split_light)
+            hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((n_wt + 255) / 256)), dim3(256), 0, st, s->dev, g, light, (int)n_wt);
         GridParams gp = g;  // the probe: this launch's first sample, natural order, one workgroup per tile, nothing stored
         gp.spp = 1;
         gp.chunks = 1;
@@ -602,8 +640,9 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
         const int wave_slots = n_cu * 4 * (one_wave ? kBezWaves : (trees ? 3 : 4));
-        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, cost, (int)n_wt, (unsigned)kmax,
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, cost, split_light ? light : nullptr, (int)n_wt, (unsigned)kmax,
                            (unsigned long long)wave_slots * (unsigned long long)heavy_div, plan, order, hidx);
+        if (split_light) g.light = light;
         g.order = order;
         g.hidx = hidx;
         g.plan = plan;
@@ -625,6 +664,26 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         HIP_TRY(hipMemsetAsync(timeline.p, 0, ((size_t)grid_dim.x + g.heavy_blocks) * 32, st));
         g.timeline = timeline.as<unsigned long long>();
     }
+    if (g.light) {
+        // the light tiles: the variant without tree / Bezier / pending-ray code on the second stream, beside the full launch
+        GridParams gl = g;
+        gl.light_mode = 1;
+        gl.hidx = nullptr;  // light tiles are never heavy
+        gl.heavy_blocks = 0;
+        gl.timeline = nullptr;
+        HIP_TRY(hipEventRecord(s->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
+        const size_t lds_light = (size_t)s->dev.n_objs * sizeof(ObjRec);
+        const dim3 gd_light((unsigned)tile_grid_blocks(g.W, g.rows, false));
+        gl.xcd_tiles = 0;
+        if (dof)
+            hipLaunchKernelGGL((trace_grid_kernel<false, false, true, false, false, false>), gd_light, dim3(kThreads), lds_light,
+                               s->aux_stream, s->dev, gl, rgb, nhit, cnt);
+        else
+            hipLaunchKernelGGL((trace_grid_kernel<false, false, false, false, false, false>), gd_light, dim3(kThreads), lds_light,
+                               s->aux_stream, s->dev, gl, rgb, nhit, cnt);
+        HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
+    }
     if (g.heavy_blocks > 0) {  // heavy workgroups in front, the tile workgroups behind them, one launch
         hipLaunchKernelGGL(pixel_const_kernel, dim3((unsigned)kmax), dim3(64), 0, st, g);
         launch_mode(std::true_type{}, g, dim3((unsigned)g.heavy_blocks + grid_dim.x), rgb, nhit, cnt);
@@ -634,6 +693,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     if (g.chunks > 1)
         hipLaunchKernelGGL(finalize_chunks_kernel, dim3((unsigned)((npx_all + 255) / 256)), dim3(256), 0, st, g, rgb, nhit);
     if (g.heavy_blocks > 0) hipLaunchKernelGGL(deferred_sum_kernel, dim3((unsigned)kmax), dim3(64), 0, st, g, rgb, nhit);
+    if (g.light) HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));  // the caller's stream continues when both launches are done
     const hipError_t launch_err = hipGetLastError();
     if (g.timeline && launch_err == hipSuccess) {
         std::vector<unsigned long long> tl(((size_t)grid_dim.x + g.heavy_blocks) * 4);
@@ -668,7 +728,7 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     g.half_width = cam->half_width; g.focus_plane = cam->focus_plane; g.lens_radius = cam->lens_radius;
     g.chunks = 1; g.chunk_spp = grid->spp; g.partial = nullptr; g.partial_nhit = nullptr;  // capture keeps one workgroup per tile
     g.timeline = nullptr;
-    g.order = nullptr; g.cost = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
+    g.light = nullptr; g.light_mode = 0; g.pad_light_ = 0; g.order = nullptr; g.cost = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
     g.probe = 0; g.heavy_blocks = 0; g.items_per_tile = 1; g.units_per_item = 256; g.maxhp = 16;
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_rec, b_cnt;

@@ -20,7 +20,7 @@ enum ObjKind : int32_t { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_MESH = 2, KIND_BE
 struct ObjRec {
     // sphere: a = centre, s0 = radius^2                       (objects.h:83-88)
     // plane : a = position, b = normal                         (objects.h:541-542)
-    // mesh  : (nothing)                                         (objects.h:470-475)
+    // mesh  : a = centre, s0 = radius^2 of a sphere around the mesh (objects.h:470-475 hold nothing; the scene walk's early-out)
     // bezier: a = position, b.x = cp[last].z, index -> BezierRec (bezier.h:303-313)
     double a[3];
     double b[3];
@@ -134,6 +134,10 @@ struct DeviceScene {
     int32_t has_glass;   // some object takes the refraction branch (main.cpp:135)
     int32_t cached_tree; // tree whose nodes every workgroup stages in LDS (-1: none)
     int32_t cached_nodes;
+    int32_t light_ok;    // every plane is diffuse and un-bumped and some object is "special" (mesh, Bezier, mirror or glass
+                         // sphere): tiles whose primary rays provably stay clear of the special objects' bounding spheres see
+                         // diffuse spheres and planes only and may be rendered by the light kernel variant (cgrt_hip.hip)
+    int32_t pad_;
 };
 
 }  // namespace cgrt

@@ -134,7 +134,7 @@ class Scene:
 
     def trace_grid(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, rows=None, row_offset=0,
                    stripe=None, sample_offset=0, spp_total=None, out=None, nhit=None, counters=None, stream=None,
-                   stats=False, accumulate=False, split_samples=False, reorder=True):
+                   stats=False, accumulate=False, split_samples=False, reorder=True, force_reorder=False):
         """Asynchronous launch on torch's current stream (or `stream`).  reorder=False: CGRT_GRID_NO_REORDER (tiles in image
         order instead of heaviest-first; same image).  split_samples: CGRT_GRID_SPLIT_SAMPLES (several
         workgroups share a tile's samples; reproducible, fp64 summation order differs from the sample-by-sample sum).  Returns (rgb, nhit, counters) torch
@@ -155,7 +155,7 @@ class Scene:
         assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (rows, width, 3)
         cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
                               spp_total, (1 if stats else 0) | (2 if accumulate else 0) | (4 if split_samples else 0) |
-                              (0 if reorder else 8))
+                              (0 if reorder else 8) | (16 if force_reorder else 0))
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         check(self._L.cgrt_trace_grid(self._h, C.byref(cc), C.byref(g), out.data_ptr(),
                                       nhit.data_ptr() if nhit is not None else None,
@@ -163,14 +163,16 @@ class Scene:
         return out, nhit, counters
 
     def trace_grid_host(self, width, height, spp=1, camera=None, max_depth=5, seed=12345, rows=None, row_offset=0,
-                        stripe=None, sample_offset=0, spp_total=None, stats=False, split_samples=False, reorder=True):
+                        stripe=None, sample_offset=0, spp_total=None, stats=False, split_samples=False, reorder=True,
+                        force_reorder=False):
         """Synchronous form with numpy outputs (no torch needed): dict(rgb, nhit, counters)."""
         rows = height - row_offset if rows is None else rows
         rgb = np.zeros((rows, width, 3), np.float32)
         nhit = np.zeros((rows, width), np.uint32)
         cnt = np.zeros((_capi.CGRT_NCOUNTERS,), np.uint64)
         cc, g = self._structs(camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
-                              spp_total, (1 if stats else 0) | (4 if split_samples else 0) | (0 if reorder else 8))
+                              spp_total, (1 if stats else 0) | (4 if split_samples else 0) | (0 if reorder else 8) |
+                              (16 if force_reorder else 0))
         check(self._L.cgrt_trace_grid_host(self._h, C.byref(cc), C.byref(g), rgb.ctypes.data, nhit.ctypes.data,
                                            cnt.ctypes.data))
         return dict(rgb=rgb, nhit=nhit, counters=cnt, nrays=int(cnt[_capi.CNT_RAYS]),

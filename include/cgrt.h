@@ -74,17 +74,24 @@ enum {
     CGRT_GRID_ACCUMULATE = 2, /* rgb += this pass instead of rgb = this pass: progressive multi-pass rendering with
                                  sample_offset / spp_total, the fp32 replacement for the reference's average.cpp,
                                  which averages nine uint8 images with truncating division (average.cpp:21-64)     */
-    CGRT_GRID_NO_REORDER = 8, /* render the tiles in image order.  By default a launch of >= 4 samples per pixel first traces
-                                 one sample of every 16x4-pixel wave tile to measure its cost, sorts the wave tiles by it and
-                                 renders heaviest first, which keeps all eight XCDs busy when a few tiles carry the work;
-                                 the image, hit counts and counters are identical either way (this flag exists to measure
-                                 the difference and to test both paths)                                              */
+    CGRT_GRID_NO_REORDER = 8, /* render every tile in image order by its own workgroup.  By default a launch of >= 4 samples
+                                 per pixel on a scene with a mesh, bump floor or Bezier object is cost-scheduled: one sample of
+                                 every 16x4-pixel wave tile is traced first to measure it; tiles that alone would hold a wave
+                                 slot for more than 1/32 of the frame's ideal duration are HEAVY and are rendered through a
+                                 queue of (pixel, sample) units that any free lane of any heavy wave takes, their Hitpoint
+                                 values parked in HBM and added per pixel afterwards in the reference's order (sample by
+                                 sample, emission order inside a sample); the other tiles follow in image order.  Image, hit
+                                 counts and counters are bit-identical either way; this flag exists to measure the difference
+                                 and to test both paths.  Device memory: up to 4 GiB of parked values per scene handle
+                                 (CGRT_DEFER_BYTES overrides)                                                         */
+    CGRT_GRID_FORCE_REORDER = 16, /* cost-schedule sphere-only scenes too (off by default: measured no gain on them)    */
     CGRT_GRID_SPLIT_SAMPLES = 4 /* let several workgroups share a tile's samples: each sums a contiguous chunk of the
                                  samples in fp64 and the chunk sums are added in chunk order by a second kernel.
                                  Reproducible, but the fp64 summation ORDER differs from the sample-by-sample sum
                                  (the last bit of a sum may differ before the rounding to fp32).  It fills the GPU
-                                 when a few tiles carry most of the work.  Scenes with a Bezier object -- whose
-                                 parity is statistical anyway -- always render this way.      */
+                                 when a few tiles carry most of the work and exactness of the last fp64 bit is not needed.
+                                 (Round 1 forced it on for Bezier scenes; the cost scheduler above now balances them
+                                 with the exact summation order, so it is purely opt-in.)                            */
 };
 
 /* indices into the uint64 counters[CGRT_NCOUNTERS] array written by cgrt_trace_grid (added to, not reset) */

@@ -540,16 +540,16 @@ def test_cost_ordered_schedule_changes_nothing(gpu_ready, name, mk, cam, W, H, s
     are not counted twice --, also in stripes, with a sample offset, with accumulation and with split samples."""
     import cgraytracing_amd as cg
     with cg.Scene(mk()) as sc:
-        a = sc.trace_grid_host(W, H, spp, cam(), 5, 77)
+        a = sc.trace_grid_host(W, H, spp, cam(), 5, 77, force_reorder=True)  # sphere scenes are scheduled only on request
         b = sc.trace_grid_host(W, H, spp, cam(), 5, 77, reorder=False)
         assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["nhit"], b["nhit"])
         assert np.array_equal(a["counters"][:2], b["counters"][:2]) and a["nrays"] >= W * H * spp
         # stripes of rank 1 of 3, second half of the samples
         kw = dict(rows=64, stripe=(8, 1, 3), sample_offset=spp // 2, spp_total=spp)
-        c = sc.trace_grid_host(W, H, spp - spp // 2, cam(), 5, 77, **kw)
+        c = sc.trace_grid_host(W, H, spp - spp // 2, cam(), 5, 77, force_reorder=True, **kw)
         d = sc.trace_grid_host(W, H, spp - spp // 2, cam(), 5, 77, reorder=False, **kw)
         assert np.array_equal(c["rgb"], d["rgb"]) and np.array_equal(c["counters"][:2], d["counters"][:2])
         if name != "vase":  # Bezier scenes always split samples
-            e = sc.trace_grid_host(W, H, 64, cam(), 5, 77, split_samples=True)
+            e = sc.trace_grid_host(W, H, 64, cam(), 5, 77, split_samples=True, force_reorder=True)
             f = sc.trace_grid_host(W, H, 64, cam(), 5, 77, split_samples=True, reorder=False)
             assert np.array_equal(e["rgb"], f["rgb"]) and np.array_equal(e["counters"][:2], f["counters"][:2])
