@@ -13,6 +13,7 @@
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -527,7 +528,10 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     static const long long env_defer_bytes = [] { const char *e = std::getenv("CGRT_DEFER_BYTES"); return e ? std::atoll(e) : 0ll; }();
     static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
     static const int env_units = [] { const char *e = std::getenv("CGRT_UNITS_PER_ITEM"); return e ? std::atoi(e) : 0; }();
-    const size_t defer_budget = env_defer_bytes > 0 ? (size_t)env_defer_bytes : ((size_t)4 << 30);  // deferred Hitpoint values, bytes
+    // deferred Hitpoint values: up to 12 GiB, at most an eighth of the device's memory (MI355X: 288 GB); allocated once per
+    // scene handle, as large as the biggest launch needed it
+    static const size_t mem_eighth = [] { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? tot / 8 : ((size_t)4 << 30); }();
+    const size_t defer_budget = env_defer_bytes > 0 ? (size_t)env_defer_bytes : std::min((size_t)12 << 30, mem_eighth);
     const int heavy_div = env_heavy_div > 0 ? env_heavy_div : 32;
     const int units_per_item = env_units > 0 ? ((env_units + 63) / 64) * 64 : 256;
     const int maxhp = glass_possible(s, grid) ? 16 : 1;  // Hitpoints per sample: a mirror chain ends in one, a glass tree of depth 5 in <= 16

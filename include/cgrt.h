@@ -82,8 +82,8 @@ enum {
                                  values parked in HBM and added per pixel afterwards in the reference's order (sample by
                                  sample, emission order inside a sample); the other tiles follow in image order.  Image, hit
                                  counts and counters are bit-identical either way; this flag exists to measure the difference
-                                 and to test both paths.  Device memory: up to 4 GiB of parked values per scene handle
-                                 (CGRT_DEFER_BYTES overrides)                                                         */
+                                 and to test both paths.  Device memory: up to 12 GiB (at most 1/8 of the device) of parked
+                                 values per scene handle, sized by the largest launch (CGRT_DEFER_BYTES overrides)    */
     CGRT_GRID_FORCE_REORDER = 16, /* cost-schedule sphere-only scenes too (off by default: measured no gain on them)    */
     CGRT_GRID_SPLIT_SAMPLES = 4 /* let several workgroups share a tile's samples: each sums a contiguous chunk of the
                                  samples in fp64 and the chunk sums are added in chunk order by a second kernel.
