@@ -104,9 +104,9 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
         wy = tile_y * (TG::H / kWaveTileH) + (NT == 256 ? (wave >> 1) : 0);
         have_tile = wx < wtiles_x && wy < wtiles_y;
         // a heavy tile is rendered by the heavy workgroups: its wave stands down here; so does the wave of a tile that
-        // belongs to the other launch of a light / full pair (the probe measures every tile)
+        // belongs to the other launch of a light / full pair (the probe leaves the light tiles out: they are never heavy)
         if (have_tile && g.hidx && g.hidx[wy * wtiles_x + wx] >= 0) have_tile = false;
-        if (have_tile && g.light && !g.probe && (g.light[wy * wtiles_x + wx] != 0) != (g.light_mode != 0)) have_tile = false;
+        if (have_tile && g.light && (g.light[wy * wtiles_x + wx] != 0) != (g.light_mode != 0)) have_tile = false;
         s_end = (g.chunks > 1) ? ((chunk + 1) * g.chunk_spp < g.spp ? (chunk + 1) * g.chunk_spp : g.spp) : g.spp;
         set_pixel(lane & 15, lane >> 4);
     }

@@ -639,6 +639,10 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         gp.probe = 1;
         gp.cost = cost;
         gp.timeline = nullptr;
+        if (split_light) {  // light tiles are not probed (plan_kernel counts them as zero); their cost entries stay unwritten
+            gp.light = light;
+            gp.light_mode = 0;
+        }
         launch(gp, dim3((unsigned)tile_blocks), nullptr, nullptr, nullptr);
         // heavy: cost x spp > (total cost x spp / wave slots) / heavy_div
         int n_cu = 256;
