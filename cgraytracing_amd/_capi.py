@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgrt.so")
+# CGRT_LIB: load another build of the same ABI instead (experiments only, e.g. tools/fma_experiment.py's libcgrt_fma.so)
+LIB_PATH = os.environ.get("CGRT_LIB") or os.path.join(_HERE, "libcgrt.so")
 
 CGRT_OK = 0
 CGRT_NCOUNTERS = 8

@@ -404,7 +404,7 @@ def test_both_hierarchies_are_exact(gpu_ready, orc, mode, monkeypatch):
     opaque = scenes.TriangleMesh.from_triangles(scenes.procedural_mesh(48, 36, (6.0, -12.0, 28.0), 6.0), (0.25, 0.25, 0.5), 0.0, 0.0, 1)
     mirror = scenes.TriangleMesh.from_triangles(scenes.procedural_mesh(24, 18, (-9.0, -13.0, 33.0), 4.0), (0.9, 0.9, 0.9), 0.8, 0.0, 1)
     objs = scenes.scene_c3(True) + [opaque, mirror]
-    W, H, spp = 96, 80, 3
+    W, H, spp = 96, 80, 4
     want = BackendScene(orc, objs).trace_grid(scenes.cam_dof(), W, H, spp, 5, seed=4242)
     sc = cg.Scene(objs)
     got = sc.trace_grid_host(W, H, spp, scenes.cam_dof(), 5, 4242)
@@ -447,7 +447,9 @@ def test_random_scenes_match_oracle_exactly(gpu_ready, orc, seed):
         tri = _random_mesh(rng, ntri, rng.uniform((-10, -16, 22), (10, 0, 34)), float(rng.uniform(3.0, 9.0)), 0.15)
         objs.append(scenes.TriangleMesh.from_triangles(tri, tuple(rng.uniform(0.2, 1.0, 3)), refl, transp, int(rng.integers(0, 3))))
     cam = scenes.cam_dof() if seed % 2 else scenes.cam_pinhole()
-    W, H, spp = 64, 48, 2
+    # spp >= 4 goes through the cost scheduler (probe, heavy-tile unit queue, ordered sum) and, when the planes are plain,
+    # the light-tile split on the second stream; spp 2 is the plain image-order launch
+    W, H, spp = 64, 48, (2 if seed % 4 == 0 else 4 + seed % 3)
     want = BackendScene(orc, objs).trace_grid(cam, W, H, spp, 5, seed=77 + seed)
     sc = cg.Scene(objs)
     got = sc.trace_grid_host(W, H, spp, cam, 5, 77 + seed)
@@ -553,3 +555,33 @@ def test_cost_ordered_schedule_changes_nothing(gpu_ready, name, mk, cam, W, H, s
             e = sc.trace_grid_host(W, H, 64, cam(), 5, 77, split_samples=True, force_reorder=True)
             f = sc.trace_grid_host(W, H, 64, cam(), 5, 77, split_samples=True, reorder=False)
             assert np.array_equal(e["rgb"], f["rgb"]) and np.array_equal(e["counters"][:2], f["counters"][:2])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_light_tile_classification_is_conservative(gpu_ready, orc, seed):
+    """The light-tile split: frames with plain diffuse planes and small "special" objects -- a mesh, a
+    mirror and a glass sphere, a Bezier vase -- placed near the frame's edge, near the camera, behind other objects and at
+    depths on both sides of the focus plane, thin lens and pinhole.  Most wave tiles are light, the objects' silhouettes
+    (blurred by the lens) must all lie in full tiles: image, hit counts and ray count equal the oracle's exactly."""
+    import cgraytracing_amd as cg
+    rng = np.random.default_rng(500 + seed)
+    objs = scenes.planes()
+    for _ in range(3):
+        c = rng.uniform((-17, -17, 2), (17, 15, 38))
+        objs.append(scenes.Sphere(tuple(c), float(rng.uniform(0.4, 2.5)), (0.9, 0.9, 0.9), 0.8, float(rng.choice([0.0, 0.5]))))
+    objs.append(scenes.Sphere(tuple(rng.uniform((-15, -15, 10), (15, 10, 35))), 2.0, (0.3, 0.5, 0.7), 0.0, 0.0))  # diffuse: not special
+    tri = _random_mesh(rng, 60, rng.uniform((-14, -16, 4), (14, 10, 36)), float(rng.uniform(1.0, 5.0)), 0.1)
+    objs.append(scenes.TriangleMesh.from_triangles(tri, (0.6, 0.7, 0.9), *[(0.0, 0.0), (0.8, 0.0), (0.8, 0.5)][seed % 3]))
+    if seed % 2:
+        objs.append(scenes.Bezier([(0, -3, 1.2), (0, 0.5, 1.2), (0, -0.5, 0), (0, 3, 0.6)], tuple(rng.uniform((-12, -10, 15), (12, 5, 30))),
+                                  (1.0, 1.0, 1.0), 0.5, 0.0))
+    cam = scenes.cam_dof() if seed % 3 else scenes.cam_pinhole()
+    W, H, spp = 256, 144, 4
+    want = BackendScene(orc, objs).trace_grid(cam, W, H, spp, 5, seed=9 + seed)
+    with cg.Scene(objs) as sc:
+        got = sc.trace_grid_host(W, H, spp, cam, 5, 9 + seed)
+        nat = sc.trace_grid_host(W, H, spp, cam, 5, 9 + seed, reorder=False)
+    assert np.array_equal(got["rgb"], nat["rgb"]) and got["nrays"] == nat["nrays"]
+    if seed % 2 == 0:  # no Bezier object: bit-exact against the oracle as well
+        assert got["nrays"] == want["nrays"] and np.array_equal(got["nhit"], want["nhit"])
+        assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
