@@ -258,6 +258,24 @@ def test_cpp_host_program_dropin(gpu_ready, orc, tmp_path):
     assert np.array_equal(got3, to_acc32(want3["acc_sum"], 2))
 
 
+def test_cpp_sharded_host_program(gpu_ready, orc, tmp_path):
+    """examples/render_sharded.cpp over include/cgrt_host_sharded.hpp (one host thread per GPU, block-cyclic stripes,
+    ncclSend/ncclRecv gather): on this one-GPU box it runs with N = 1 -- scene replicated once, whole frame, no communicator --
+    and must give the oracle's frame; the N > 1 path is the same code plus the grouped gather and is unverified here."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cgraytracing_amd", "cgrt_sharded")
+    assert os.path.exists(exe), "build it with make -C cgraytracing_amd/csrc all"
+    raw = str(tmp_path / "c2.f32")
+    out = subprocess.run([exe, "--gpus", "1", "--width", "160", "--height", "88", "--spp", "4", "--dof", "--raw", raw],
+                         capture_output=True, text=True, check=True).stdout
+    want = BackendScene(orc, scenes.scene_c2()).trace_grid(scenes.cam_dof(), 160, 88, 4, 5, seed=12345)
+    got = np.fromfile(raw, np.float32).reshape(88, 160, 3)
+    assert np.array_equal(got, to_acc32(want["acc_sum"], 4))
+    assert "gpus: 1 rays: %d " % want["nrays"] in out
+
+
 def _canon(hp, pix, smp):
     """Order-independent form of a hitpoint stream: sort by (pixel, sample, f, pos, normal)."""
     keys = [hp[:, k] for k in range(8, -1, -1)] + [smp, pix]
