@@ -215,6 +215,20 @@ void HostTree::build(bool opaque, bool with_bvh) {
     tris.resize(n);
     leaf_ids.resize(n);
     b.emit(0, n, 0, 0, 0);
+    // per-triangle boxes in leaf order (cgrt_traverse.hpp, leaf scan): a triangle can only be hit at a point of its own
+    // box, so the grown box is a superset test exactly like the nodes' 
+    tboxes.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        const double *t = &tri9[9 * (size_t)leaf_ids[k]];
+        NodeRec nr;
+        for (int c = 0; c < 3; c++) {
+            nr.lo[c] = round_down(lo3(t[c], t[3 + c], t[6 + c]) - kBoxPad);
+            nr.hi[c] = round_up(hi3(t[c], t[3 + c], t[6 + c]) + kBoxPad);
+        }
+        nr.skip = 0;
+        nr.leaf = 0;
+        tboxes[k] = nr;
+    }
     if (with_bvh) build_bvh(opaque);
 }
 

@@ -24,6 +24,7 @@ struct HostTree {
     //          for rays of that octant), see build_bvh()
     std::vector<NodeRec> nodes;
     std::vector<TriRec> tris;
+    std::vector<NodeRec> tboxes;  // one grown, outward-rounded fp32 box per triangle of tris[] (the leaf scan's cheap pre-test)
     std::vector<NodeRec> bvh;
     int32_t bvh_nodes = 0;
     // opaque owner (transparency < eps): only the nearest hit matters, so the hierarchy goes down to small groups of

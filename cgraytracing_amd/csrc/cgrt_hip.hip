@@ -219,6 +219,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     std::vector<HFieldRec> hfields;
     std::vector<HCellRec> hcells;
     std::vector<OTriRec> otris;
+    std::vector<NodeRec> tboxes;
     for (auto &t : H.trees) {
         TreeRec tr;
         tr.node_begin = (int64_t)nodes.size();
@@ -242,6 +243,8 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
             hfields.push_back(hf);
             hcells.insert(hcells.end(), t.hcells.begin(), t.hcells.end());
         }
+        tr.tbox_begin = (int64_t)tboxes.size();
+        tboxes.insert(tboxes.end(), t.tboxes.begin(), t.tboxes.end());
         nodes.insert(nodes.end(), dev_nodes.begin(), dev_nodes.end());
         tris.insert(tris.end(), t.tris.begin(), t.tris.end());
         trees.push_back(tr);
@@ -278,6 +281,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         if ((rc = upload(s, hfields, &d.hfields))) return rc;
         if ((rc = upload(s, hcells, &d.hcells))) return rc;
         if ((rc = upload(s, otris, &d.otris))) return rc;
+        if ((rc = upload(s, tboxes, &d.tboxes))) return rc;
         return CGRT_OK;
     };
     if (all_uploads() != CGRT_OK) {

@@ -77,6 +77,7 @@ struct TreeRec {
     int32_t tri_level;   // 1: the hierarchy is over single triangles (opaque owner), leaves index otris[]; 0: over the
                          // reference's leaves, leaves index tris[]
     int32_t pad;
+    int64_t tbox_begin;  // into tboxes[]: one box per triangle of tris[], same order
 };
 
 // A bump-mapped floor's displacement mesh (objects.h:482-503) is a height field over a regular x-z grid: one quad per
@@ -127,6 +128,7 @@ struct DeviceScene {
     const HFieldRec *hfields;
     const HCellRec *hcells;
     const OTriRec *otris;
+    const NodeRec *tboxes;
     int32_t n_objs, n_trees, n_texs, n_beziers;
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
     int32_t has_bezier;
