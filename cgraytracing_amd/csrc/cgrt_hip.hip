@@ -554,13 +554,21 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     size_t chunk_bytes = 0;
     if (g.chunks > 1) chunk_bytes = (size_t)g.chunks * npx_all * (3 * sizeof(double) + sizeof(uint32_t));
     const size_t chunk_bytes_al = (chunk_bytes + 255) & ~(size_t)255;
-    const size_t scratch_need = chunk_bytes_al + sched_bytes + defer_bytes;
+    const size_t per_tile = tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst;
+    size_t scratch_need = chunk_bytes_al + sched_bytes + defer_bytes;
     if (scratch_need > 0 && s->scratch_bytes < scratch_need) {
         if (s->scratch) (void)hipFree(s->scratch);
         s->scratch = nullptr;
         s->scratch_bytes = 0;
-        if (hipMalloc(&s->scratch, scratch_need) != hipSuccess)
-            return fail(CGRT_ERR_DEVICE, "cannot allocate launch scratch (chunk sums / schedule / deferred Hitpoint values)");
+        // a device short of memory gets a smaller deferred buffer (fewer heavy tiles, same image) before it gets an error
+        while (hipMalloc(&s->scratch, scratch_need) != hipSuccess) {
+            (void)hipGetLastError();
+            s->scratch = nullptr;
+            if (kmax == 0) return fail(CGRT_ERR_DEVICE, "cannot allocate launch scratch (chunk sums / schedule / deferred Hitpoint values)");
+            kmax /= 2;
+            defer_bytes = kmax ? kmax * per_tile + 256 : 0;
+            scratch_need = chunk_bytes_al + sched_bytes + defer_bytes;
+        }
         s->scratch_bytes = scratch_need;
     }
     if (g.chunks > 1) {

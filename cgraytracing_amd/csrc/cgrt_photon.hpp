@@ -25,6 +25,10 @@
 namespace {
 
 constexpr int kSegStride = 8;          // event slots per photon (MAX_DEPTH = 5 segments)
+#ifndef CGRT_PHOTON_WAVES
+#define CGRT_PHOTON_WAVES 4
+#endif
+constexpr int kPhotonWaves = CGRT_PHOTON_WAVES;  // waves per SIMD photon_trace_kernel<false> is compiled for
 constexpr double kPiRef = 3.14159265358979;  // main.cpp:26
 
 struct PhotonArgs {
@@ -102,7 +106,7 @@ __device__ __forceinline__ V3 sample_sphere(Stream &rs) {
 
 // 1. photon paths.  events: count*kSegStride records of 9 doubles; valid: same count of bytes.
 template <bool BEZ>
-__global__ __launch_bounds__(kThreads, BEZ ? 2 : 4) void photon_trace_kernel(DeviceScene sc, PhotonArgs pa, double *__restrict__ events,
+__global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace_kernel(DeviceScene sc, PhotonArgs pa, double *__restrict__ events,
                                                                    unsigned char *__restrict__ valid) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw);
