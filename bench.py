@@ -192,7 +192,8 @@ def other_configs(dev_index):
         sc = cg.Scene(objs, device=dev_index)
         buf = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:%d" % dev_index)
         cnt = torch.zeros(8, dtype=torch.int64, device=buf.device)
-        sc.trace_grid(w, h, 1, cam, DEPTH, SEED, out=buf, nhit=False, counters=cnt)  # warm-up: one sample per pixel
+        # warm-up: the same launch once (a scheduled launch sizes the scene handle's scratch by its sample count on first use)
+        sc.trace_grid(w, h, spp, cam, DEPTH, SEED, out=buf, nhit=False, counters=cnt)
         torch.cuda.synchronize()
         cnt.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -419,7 +419,7 @@ static GridVariant grid_variant(const cgrt_scene *s, const cgrt_camera *cam, con
     v.sph = !v.trees && s->dev.all_spheres != 0;
     v.stats = (grid->flags & CGRT_GRID_STATS) != 0 && s->dev.has_mesh != 0 && !v.bez;
     v.nt = v.bez ? 64 : kThreads;
-    v.sched = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER)) &&
+    v.sched = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER)) &&  // (CGRT_FORCE_REORDER, a measurement aid, is not reflected here)
               ((size_t)((grid->width + kWaveTileW - 1) / kWaveTileW) * ((grid->rows + kWaveTileH - 1) / kWaveTileH)) > 1;
     return v;
 }
@@ -523,12 +523,13 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     // costs 1/spp of the frame and the whole scheme is skipped below 4 samples per pixel or on request (CGRT_GRID_NO_REORDER).
     const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW, wtiles_y = (g.rows + kWaveTileH - 1) / kWaveTileH;
     const size_t n_wt = (size_t)wtiles_x * wtiles_y;
+    static const bool env_force_reorder = [] { const char *e = std::getenv("CGRT_FORCE_REORDER"); return e && *e && *e != '0'; }();
     // Sphere-only scenes are left in image order: without a tree or a Newton solve behind a ray, a tile's cost varies only
     // with the size of its ray trees (<= 31 rays per sample), the per-lane sample loop already keeps 97 % of the lanes busy,
     // and measured on C2 the unit queue costs 13 % more VALU instructions (at 93 % VALU busy) and 0.9 GB of deferred values
     // per frame for a gain within the noise (4.0-4.2 ms either way).
     const bool reorder = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && n_wt > 1 && n_wt < (1u << 30) &&
-                         (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER));
+                         (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER) || env_force_reorder);
     static const long long env_defer_bytes = [] { const char *e = std::getenv("CGRT_DEFER_BYTES"); return e ? std::atoll(e) : 0ll; }();
     static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
     static const int env_units = [] { const char *e = std::getenv("CGRT_UNITS_PER_ITEM"); return e ? std::atoi(e) : 0; }();
