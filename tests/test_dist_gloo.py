@@ -132,3 +132,29 @@ def test_striped_ppm_gather_world2():
         assert p.exitcode == 0
     want = (_pattern(list(range(H)), W).double() * (1.0 + 1e-12)).numpy()
     assert frame.dtype == np.float64 and np.array_equal(frame, want)
+
+
+def test_assemble_partial_shares():
+    """Weak scaling of a frame defined on 8 shares (bench.py --config c5): with fewer ranks than shares the gathered buffers
+    fill only their own stripes; the stripes of absent shares stay zero and the row order is the global one."""
+    S, shares, n, W, H = 16, 8, 3, 4, 16 * 8 * 2
+    rows_local = local_rows(H, S, 0, shares)
+    gathered = torch.stack([_pattern([global_row(j, S, r, shares) for j in range(rows_local)], W) for r in range(n)])
+    frame = assemble(gathered, H, S, shares)
+    want = _pattern(list(range(H)), W)
+    owner = (torch.arange(H) // S) % shares
+    want[owner >= n] = 0
+    assert frame.shape == (H, W, 3) and torch.equal(frame, want)
+    # all shares present: the plain permutation
+    full = torch.stack([_pattern([global_row(j, S, r, shares) for j in range(rows_local)], W) for r in range(shares)])
+    assert torch.equal(assemble(full, H, S, shares), _pattern(list(range(H)), W))
+
+
+def test_striped_renderer_shares_without_process_group():
+    """One process, 8 shares (bench.py --config c5 --gpus 1): the renderer owns share 0, gather() returns the partial frame."""
+    sr = StripedRenderer(4, 256, stripe_rows=16, nshares=8)
+    assert sr.nranks == 1 and sr.nshares == 8 and sr.rows_local == 32 and sr.stripe == (16, 0, 8)
+    local = _pattern([global_row(j, 16, 0, 8) for j in range(32)], 4)
+    frame = sr.gather(local)
+    assert frame.shape == (256, 4, 3)
+    assert torch.equal(frame[:16], local[:16]) and torch.equal(frame[128:144], local[16:]) and not frame[16:128].any()
