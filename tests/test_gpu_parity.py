@@ -325,6 +325,14 @@ def test_progressive_accumulation(gpu_ready, orc):
     want = to_acc32(o.trace_grid(cam, W, H, spp, 5, 21)["acc_sum"], spp)
     assert np.array_equal(one.cpu().numpy(), want)
     assert np.abs(acc.cpu().numpy() - want).max() < 2e-6
+    # passes of 4 samples are cost-scheduled (heavy tiles through the ordered sum, light tiles on the second stream): the
+    # accumulated frame must equal, bit for bit, the same passes rendered in image order
+    a, b = torch.zeros_like(one), torch.zeros_like(one)
+    for p in range(2):
+        sc.trace_grid(W, H, 4, cam, 5, 21, sample_offset=4 * p, spp_total=spp, out=a, accumulate=True)
+        sc.trace_grid(W, H, 4, cam, 5, 21, sample_offset=4 * p, spp_total=spp, out=b, accumulate=True, reorder=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float((a - one).abs().max()) < 2e-6
     sc.close()
 
 
