@@ -2,6 +2,8 @@
 cannot render them in test time): sharding invariance, sample-range additivity, run-to-run determinism,
 oracle agreement on crops, and counter identities.  Plus the edge cases: empty scene, 1x1 image, widest row,
 the 96-object limit."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -95,6 +97,27 @@ def test_c4_shape_dragon_stripes(gpu_ready, orc):
     sc.close()
 
 
+def test_c4_full_configuration(gpu_ready, orc):
+    """configs[3] exactly as BASELINE.json names it on one GPU -- 4096 x 4096, spp 256, dragon, thin lens (the frame
+    `bench.py --config c4` times; cost-scheduled: probe, ~18 000 heavy wave tiles through the unit queue and the ordered
+    sum, light tiles on the second stream): ray count = one per sample, and rows through the dragon's head, body and the
+    floor in front of it equal the oracle's at the full 256 samples, bit for bit, as does one of the 8 ranks' stripes."""
+    import cgraytracing_amd as cg
+    W, H, spp = 4096, 4096, 256
+    cam = scenes.cam_dof()
+    with cg.Scene(scenes.scene_dragon()) as sc:
+        full, nhit, cnt = _frame(sc, W, H, spp, cam)
+        assert int(cnt[0]) == W * H * spp and int(cnt[1]) == int(nhit.view(torch.int32).to(torch.int64).sum())
+        o = BackendScene(orc, scenes.scene_dragon())
+        for r0 in (700, 1100, 1500):
+            want = o.trace_grid(cam, W, H, spp, 5, 12345, row0=r0, nrows=1)
+            assert np.array_equal(full[r0:r0 + 1].cpu().numpy(), to_acc32(want["acc_sum"], spp)), r0
+        N, S, r = 8, 16, 3
+        part, _, _ = _frame(sc, W, H, spp, cam, rows=local_rows(H, S, r, N), stripe=(S, r, N))
+        rows = [((j // S) * N + r) * S + j % S for j in range(local_rows(H, S, r, N))]
+        assert torch.equal(part, full[torch.as_tensor(rows, device=full.device)])
+
+
 def test_c5_shape_bump_and_bezier(gpu_ready, orc):
     """configs[4] shape: 8192-wide rows, stone-sized bump floor (146 744 triangles) + Bezier vase, one GPU's
     share reduced to 8192 x 64 rows and spp 4."""
@@ -115,6 +138,24 @@ def test_c5_shape_bump_and_bezier(gpu_ready, orc):
     ok = np.abs(got[:2].cpu().numpy() - to_acc32(want["acc_sum"], spp)).max(axis=-1) < 1e-4
     assert ok.mean() > 0.999, ok.mean()
     sc.close()
+
+
+def test_c5_full_sample_count_stripe(gpu_ready):
+    """configs[4] at its FULL sample count on one 16-row stripe of the 8192 x 8192 frame through the Bezier vase: spp 1024,
+    the reference's real stone.jpg bump floor (146 744 triangles), thin lens.  At this sample count a heavy tile is 65 536
+    units in 256 items; the scheduled launch (vase tiles through the unit queue, values parked and summed in order) must
+    equal the image-order launch -- one lane per pixel running its 1024 samples in sequence -- bit for bit, in image and ray
+    count.  (The oracle runs one row per thread: a single 8192-pixel row at 1024 samples is ~3 minutes of CPU, so agreement
+    with the oracle on this scene is checked at 4 samples in test_c5_shape_bump_and_bezier; Bezier parity is statistical.)"""
+    import cgraytracing_amd as cg
+    W, H, spp, r0 = 8192, 8192, 1024, 3968
+    cam = scenes.cam_dof()
+    objs = scenes.scene_c5(scenes.stone_texture())
+    with cg.Scene(objs) as sc:
+        got, _, cnt = _frame(sc, W, H, spp, cam, rows=16, row_offset=r0)
+        nat = sc.trace_grid_host(W, H, spp, cam, 5, 12345, rows=16, row_offset=r0, reorder=False)
+    assert np.array_equal(got.cpu().numpy(), nat["rgb"]) and int(cnt[0]) == nat["nrays"]
+    assert int(cnt[0]) > W * 16 * spp  # the vase reflects: secondary rays
 
 
 def test_edge_cases(gpu_ready, orc):
