@@ -613,6 +613,53 @@ int HostScene::add_plane(const double p[3], const double n[3], const double sc[3
     return (int)objs.size() - 1;
 }
 
+// Spheres around groups of triangles: the set is halved `depth` times at the median centroid along the longest axis of
+// the group's vertices; each group gives (centre of its vertices' box, largest vertex distance + 1e-3).  out: 4 doubles each.
+static constexpr int kCoverDepth = 6;
+static void cover_spheres(const std::vector<double> &tri9, int depth, std::vector<double> &out) {
+    const size_t n = tri9.size() / 9;
+    if (n == 0) return;
+    std::vector<uint32_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
+    struct Range { size_t b, e; int d; };
+    std::vector<Range> todo{{0, n, depth}};
+    while (!todo.empty()) {
+        const Range r = todo.back();
+        todo.pop_back();
+        double lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+        for (size_t i = r.b; i < r.e; i++) {
+            const double *t = &tri9[9 * (size_t)idx[i]];
+            for (int v = 0; v < 9; v++) {
+                lo[v % 3] = std::min(lo[v % 3], t[v]);
+                hi[v % 3] = std::max(hi[v % 3], t[v]);
+            }
+        }
+        if (r.d > 0 && r.e - r.b >= 128) {
+            int ax = 0;
+            for (int k = 1; k < 3; k++)
+                if (hi[k] - lo[k] > hi[ax] - lo[ax]) ax = k;
+            const size_t mid = r.b + (r.e - r.b) / 2;
+            std::nth_element(idx.begin() + r.b, idx.begin() + mid, idx.begin() + r.e, [&](uint32_t a, uint32_t b) {
+                const double *ta = &tri9[9 * (size_t)a], *tb = &tri9[9 * (size_t)b];
+                return ta[ax] + ta[3 + ax] + ta[6 + ax] < tb[ax] + tb[3 + ax] + tb[6 + ax];
+            });
+            todo.push_back({r.b, mid, r.d - 1});
+            todo.push_back({mid, r.e, r.d - 1});
+            continue;
+        }
+        const double c[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+        double r2 = 0;
+        for (size_t i = r.b; i < r.e; i++) {
+            const double *t = &tri9[9 * (size_t)idx[i]];
+            for (int v = 0; v < 3; v++) {
+                const double dx = t[3 * v] - c[0], dy = t[3 * v + 1] - c[1], dz = t[3 * v + 2] - c[2];
+                r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+            }
+        }
+        out.insert(out.end(), {c[0], c[1], c[2], std::sqrt(r2) + 1e-3});
+    }
+}
+
 int HostScene::add_mesh_triangles(const double *tri9, int ntri, const double sc[3], double refl, double transp,
                                   int type) {
     if (ntri < 0 || (ntri > 0 && !tri9)) { error = "mesh: bad triangle array"; return -1; }
@@ -621,21 +668,22 @@ int HostScene::add_mesh_triangles(const double *tri9, int ntri, const double sc[
     HostTree tree;
     tree.tri9.assign(tri9, tri9 + (size_t)ntri * 9);
     tree.build(transp < kEps);  // objects.h:402; an opaque owner gets the triangle-level hierarchy
-    {   // bounding sphere of the mesh (a = centre, s0 = radius^2): the scene walk's division-free early-out.  It contains the
-        // root box grown by more than the box test's 1e-4 slack, so a ray that misses it cannot touch any node.
-        double lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
-        for (size_t i = 0; i < tree.tri9.size(); i++) {
-            lo[i % 3] = std::min(lo[i % 3], tree.tri9[i]);
-            hi[i % 3] = std::max(hi[i % 3], tree.tri9[i]);
+    {   // bounding sphere of the mesh (a = centre, s0 = radius^2): the scene walk's division-free early-out.  A triangle can
+        // only be hit at one of its own points, so a sphere around every vertex (plus 1e-3, far above the triangle test's
+        // rounding) is enough: a ray that misses it cannot hit, whatever boxes it crosses.
+        const size_t first = cover.size();
+        cover_spheres(tree.tri9, 0, cover);
+        if (ntri == 0) {
+            o.a[0] = o.a[1] = o.a[2] = 0;
+            o.s0 = -1.0;  // empty mesh: nothing to hit
+        } else {
+            for (int k = 0; k < 3; k++) o.a[k] = cover[first + k];
+            o.s0 = cover[first + 3] * cover[first + 3] * (1 + 1e-9);
+            cover.resize(first);
+            // the same bound in pieces (<= 2^kCoverDepth spheres over median-split groups of triangles), for classify_kernel:
+            // a long thin mesh fills a small part of its one sphere's silhouette
+            cover_spheres(tree.tri9, kCoverDepth, cover);
         }
-        double r2 = 0;
-        for (int k = 0; k < 3; k++) {
-            if (ntri == 0) { lo[k] = hi[k] = 0; }
-            o.a[k] = 0.5 * (lo[k] + hi[k]);
-            const double h = 0.5 * (hi[k] - lo[k]) + 1e-3;
-            r2 += h * h;
-        }
-        o.s0 = ntri == 0 ? -1.0 : r2 * (1 + 1e-9);  // empty mesh: nothing to hit
     }
     trees.push_back(std::move(tree));
     o.tree = (int)trees.size() - 1;

@@ -53,6 +53,7 @@ struct HostScene {
     std::vector<HostTree> trees;
     std::vector<HostTexture> textures;
     std::vector<BezierRec> beziers;
+    std::vector<double> cover;  // (cx, cy, cz, r) spheres that together contain every mesh triangle (classify_kernel)
     std::string error;
 
     int add_sphere(const double c[3], double r, const double sc[3], double refl, double transp);

@@ -523,7 +523,9 @@ __global__ void finalize_chunks_kernel(GridParams g, float *__restrict__ rgb, ui
 // code renders it exactly.  Conservative bound: the tile's pinhole directions lie in a cone around its centre direction
 // (half-angle = 1.5 x the largest corner deviation + 1e-6); a thin-lens ray deviates from its pinhole ray, at depth z, by
 // lens_radius * |1 - (z - cam.z) / (focus_plane - cam.z)| sideways, so the object's sphere is grown by the largest such
-// deviation over its depth range.  Anything doubtful (object behind or around the camera, rows beyond the image) is FULL.
+// deviation over its depth range.  A mesh is bounded by its cover spheres (DeviceScene::cover: up to 64 spheres over
+// median-split groups of its triangles -- a long thin mesh fills little of one sphere around all of it).  Anything doubtful
+// (object behind or around the camera, rows beyond the image) is FULL.
 __global__ void classify_kernel(DeviceScene sc, GridParams g, unsigned char *__restrict__ light, int n_wt) {
     const int wt = blockIdx.x * blockDim.x + threadIdx.x;
     if (wt >= n_wt) return;
@@ -547,40 +549,37 @@ __global__ void classify_kernel(DeviceScene sc, GridParams g, unsigned char *__r
     const double alpha = 1.5 * acos(cmin) + 1e-6;
     bool is_light = true;
     // the stripe mapping keeps a wave tile's four rows adjacent (stripes are multiples of 8 rows), so the corners bound it
-    for (int i = 0; i < sc.n_objs && is_light; i++) {
-        const ObjRec &ob = sc.objs[i];
-        V3 c;
-        double r;
-        if (ob.kind == KIND_SPHERE) {
-            if (ob.refl < kEps && ob.transp < kEps) continue;  // diffuse: no secondary rays
-            c = ld3(ob.a);
-            r = sqrt(ob.s0);
-        } else if (ob.kind == KIND_MESH) {
-            if (ob.s0 < 0) continue;  // empty mesh
-            c = ld3(ob.a);
-            r = sqrt(ob.s0);
-        } else if (ob.kind == KIND_BEZIER) {
-            const BezierRec &bz = sc.beziers[ob.aux];
-            c = mk(0.5 * (bz.box[0] + bz.box[1]), 0.5 * (bz.box[2] + bz.box[3]), 0.5 * (bz.box[4] + bz.box[5]));
-            const V3 hw = mk(0.5 * (bz.box[1] - bz.box[0]), 0.5 * (bz.box[3] - bz.box[2]), 0.5 * (bz.box[5] - bz.box[4]));
-            r = sqrt(dot(hw, hw)) + 1e-3;
-        } else {
-            continue;  // planes: vetted by light_ok
-        }
+    // false: the sphere (c, r) may be touched by a primary ray of the tile
+    auto clear_of = [&](V3 c, double r) {
         r = r * (1 + 1e-9) + 1e-6;
         if (g.lens_radius > 0) {
             const double f = g.focus_plane - cam.z;
             const double s_lo = (c.z - r - cam.z) / f, s_hi = (c.z + r - cam.z) / f;
-            if (!(f > 0) || !(s_lo > 0)) { is_light = false; break; }  // object reaches the lens plane or behind it
+            if (!(f > 0) || !(s_lo > 0)) return false;  // object reaches the lens plane or behind it
             r += g.lens_radius * fmax(fabs(1 - s_lo), fabs(1 - s_hi));
         }
         const V3 v = c - cam;
         const double dist = sqrt(dot(v, v));
-        if (!(dist > r)) { is_light = false; break; }
+        if (!(dist > r)) return false;
         double ct = dot(dc, v) / dist;
         ct = fmin(1.0, fmax(-1.0, ct));
-        if (acos(ct) <= alpha + asin(r / dist) + 1e-6) is_light = false;
+        return !(acos(ct) <= alpha + asin(r / dist) + 1e-6);
+    };
+    for (int i = 0; i < sc.n_objs && is_light; i++) {
+        const ObjRec &ob = sc.objs[i];
+        if (ob.kind == KIND_SPHERE) {
+            if (ob.refl < kEps && ob.transp < kEps) continue;  // diffuse: no secondary rays
+            is_light = clear_of(ld3(ob.a), sqrt(ob.s0));
+        } else if (ob.kind == KIND_BEZIER) {
+            const BezierRec &bz = sc.beziers[ob.aux];
+            const V3 hw = mk(0.5 * (bz.box[1] - bz.box[0]), 0.5 * (bz.box[3] - bz.box[2]), 0.5 * (bz.box[5] - bz.box[4]));
+            is_light = clear_of(mk(0.5 * (bz.box[0] + bz.box[1]), 0.5 * (bz.box[2] + bz.box[3]), 0.5 * (bz.box[4] + bz.box[5])),
+                                sqrt(dot(hw, hw)) + 1e-3);
+        }
+        // planes: vetted by light_ok; meshes: the cover spheres below
     }
+    for (int i = 0; i < sc.n_cover && is_light; i++)
+        is_light = clear_of(mk(sc.cover[4 * i], sc.cover[4 * i + 1], sc.cover[4 * i + 2]), sc.cover[4 * i + 3]);
     light[wt] = is_light ? 1 : 0;
 }
 

@@ -282,6 +282,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         if ((rc = upload(s, hcells, &d.hcells))) return rc;
         if ((rc = upload(s, otris, &d.otris))) return rc;
         if ((rc = upload(s, tboxes, &d.tboxes))) return rc;
+        if ((rc = upload(s, H.cover, &d.cover))) return rc;
         return CGRT_OK;
     };
     if (all_uploads() != CGRT_OK) {
@@ -295,6 +296,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     d.n_trees = (int32_t)trees.size();
     d.n_texs = (int32_t)texs.size();
     d.n_beziers = (int32_t)H.beziers.size();
+    d.n_cover = (int32_t)(H.cover.size() / 4);
     d.has_mesh = trees.empty() ? 0 : 1;
     d.has_bezier = H.beziers.empty() ? 0 : 1;
     d.cached_tree = -1;
@@ -320,7 +322,6 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
             if (o.kind == KIND_MESH || o.kind == KIND_BEZIER || (o.kind == KIND_SPHERE && !diffuse)) special = true;
         }
         d.light_ok = (planes_plain && special && !d.all_spheres) ? 1 : 0;
-        d.pad_ = 0;
         if (d.light_ok && !s->aux_stream) {
             if (hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -129,6 +129,7 @@ struct DeviceScene {
     const HCellRec *hcells;
     const OTriRec *otris;
     const NodeRec *tboxes;
+    const double *cover;  // n_cover x (cx, cy, cz, r): spheres that together contain every mesh triangle
     int32_t n_objs, n_trees, n_texs, n_beziers;
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
     int32_t has_bezier;
@@ -139,7 +140,7 @@ struct DeviceScene {
     int32_t light_ok;    // every plane is diffuse and un-bumped and some object is "special" (mesh, Bezier, mirror or glass
                          // sphere): tiles whose primary rays provably stay clear of the special objects' bounding spheres see
                          // diffuse spheres and planes only and may be rendered by the light kernel variant (cgrt_hip.hip)
-    int32_t pad_;
+    int32_t n_cover;
 };
 
 }  // namespace cgrt
