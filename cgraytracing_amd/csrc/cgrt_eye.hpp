@@ -96,10 +96,16 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
         // 8x8 per wave measured: meshes equal, C2 7 % slower.  When a tile's samples are split over several workgroups
         // (chunks > 1) the chunk index comes from the block index too.
         const int nb = tile_block;
-        const int tile_blocks = tile_grid / g.chunks;
-        chunk = nb / tile_blocks;
         int tile_x, tile_y;
-        if (!tile_of_block(g, nb % tile_blocks, tile_x, tile_y, TG::W, TG::H)) return;  // whole workgroup (no later barrier is missed)
+        if (tile_grid < 0) {  // an entry of the tile queue: the tile's number itself
+            const int tiles_x = (g.W + TG::W - 1) / TG::W;
+            tile_x = nb % tiles_x;
+            tile_y = nb / tiles_x;
+        } else {
+            const int tile_blocks = tile_grid / g.chunks;
+            chunk = nb / tile_blocks;
+            if (!tile_of_block(g, nb % tile_blocks, tile_x, tile_y, TG::W, TG::H)) return;  // whole workgroup (no later barrier is missed)
+        }
         wx = tile_x * (TG::W / kWaveTileW) + (NT == 256 ? (wave & 1) : 0);
         wy = tile_y * (TG::H / kWaveTileH) + (NT == 256 ? (wave >> 1) : 0);
         have_tile = wx < wtiles_x && wy < wtiles_y;
@@ -426,13 +432,13 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
         __syncthreads();
         atomicAdd(&tl_rays, my_rays);
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0) {  // a workgroup that serves queues passes here once per tile / per queue: first start, last end, all rays
             unsigned long long *q = g.timeline + 4 * (size_t)blockIdx.x;
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-            q[0] = (unsigned long long)tl_t0;
+            if (q[0] == 0ull) q[0] = (unsigned long long)tl_t0;
             q[1] = (unsigned long long)wall_clock64();
             q[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
-            q[3] = (unsigned long long)(wx & 0xffff) | ((unsigned long long)(wy & 0xffff) << 16) | ((unsigned long long)tl_rays << 32);
+            q[3] = ((unsigned long long)(wx & 0xffff) | ((unsigned long long)(wy & 0xffff) << 16)) + ((q[3] >> 32) << 32) + ((unsigned long long)tl_rays << 32);
         }
     }
     if (counters) {
@@ -479,12 +485,46 @@ __global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? 3 : 4)) void trace_g
                                                                                          uint32_t *__restrict__ nhit_out,
                                                                                          unsigned long long *__restrict__ counters) {
     const HitpointSink none{nullptr, nullptr, 0};
-    if ((int)blockIdx.x < g.heavy_blocks)
-        trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, counters, none, 0, 1);
-    else
-        trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, false>(sc, g, rgb, nhit_out, counters, none,
-                                                                              (int)blockIdx.x - g.heavy_blocks,
-                                                                              (int)gridDim.x - g.heavy_blocks);
+    const bool heavy_first = (int)blockIdx.x < g.heavy_blocks;
+    if (NT == 64) {
+        // one-wave workgroups (Bezier scenes): one workgroup per 16x4 tile behind the heavy ones -- a slot is handed on the
+        // moment its wave ends, and measured on a C5 band the queue form bought nothing (34.6 vs 34.9 ms) while its larger
+        // kernel cost 4 %
+        if (heavy_first)
+            trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, counters, none, 0, 1);
+        else
+            trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, false>(sc, g, rgb, nhit_out, counters, none,
+                                                                                  (int)blockIdx.x - g.heavy_blocks,
+                                                                                  (int)gridDim.x - g.heavy_blocks);
+        return;
+    }
+    // With a tile queue (g.border) both kinds of work come from queues: a workgroup serves its own kind until that queue is
+    // empty, then the other.  Without one (split samples) a workgroup behind the heavy ones renders the one tile its index names.
+    // Each body appears once in the code: the loop runs them in either order.
+    const bool queued = g.border != nullptr;
+    __shared__ unsigned tile_entry;
+    for (int phase = 0; phase < 2; phase++) {
+        if ((phase == 0) == heavy_first) {
+            if (queued || heavy_first)
+                trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, counters, none, 0, 1);
+        } else {
+            const unsigned n_entries = queued ? load_uniform(g.plan + 3) : (heavy_first ? 0u : 1u);
+            unsigned served = 0;
+            while (true) {
+                unsigned e = served++;
+                if (queued) {
+                    __syncthreads();  // every wave is done with the previous tile (and has read tile_entry)
+                    if (threadIdx.x == 0) tile_entry = atomicAdd(&g.plan[4], 1u);
+                    __syncthreads();
+                    e = tile_entry;
+                }
+                if (e >= n_entries) break;
+                trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, false>(
+                    sc, g, rgb, nhit_out, counters, none, queued ? (int)g.border[e] : (int)blockIdx.x - g.heavy_blocks,
+                    queued ? -1 : (int)gridDim.x - g.heavy_blocks);
+            }
+        }
+    }
 }
 
 // CGRT_GRID_SPLIT_SAMPLES, second step: chunk sums added in chunk order, scaled, rounded once to fp32.
@@ -589,10 +629,12 @@ __global__ void classify_kernel(DeviceScene sc, GridParams g, unsigned char *__r
 // of the frame's ideal duration.  At most kmax tiles can be heavy (what the deferred buffers hold): if more exceed the
 // threshold it is raised, on a quarter-octave histogram of the costs, until the count fits -- the heaviest stay.
 // Output: order[0..K) = the heavy wave tiles, heaviest histogram bin first, hidx[wave tile] = rank or -1, plan[0] = K,
-// plan[1] = threshold, plan[2] = 0 (the item queue's head).
+// plan[1] = threshold, plan[2] = 0 (the item queue's head); with `border`: the tile queue (GridParams::border), plan[3] = its
+// length, plan[4] = 0 (its head).
 __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__ cost_in, const unsigned char *__restrict__ light, int n,
                                                     unsigned kmax, unsigned long long divisor, uint32_t *__restrict__ plan,
-                                                    uint32_t *__restrict__ order, int32_t *__restrict__ hidx) {
+                                                    uint32_t *__restrict__ order, int32_t *__restrict__ hidx,
+                                                    uint32_t *__restrict__ border, int wtiles_x, int wtiles_y, int tw, int th) {
     // a light tile (rendered by the other launch) counts for nothing here
     auto cost = [&](int i) -> uint32_t { return (light && light[i]) ? 0u : cost_in[i]; };
     __shared__ unsigned long long part[1024];
@@ -669,6 +711,50 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         plan[0] = base_s;
         plan[1] = (uint32_t)(thr > 0xffffffffull ? 0xffffffffull : thr);
         plan[2] = 0;
+        plan[3] = 0;
+        plan[4] = 0;
+    }
+    if (!border) return;
+    // The tile queue: tiles of tw x th wave tiles (one workgroup's worth) with something left to render -- a wave tile that is
+    // neither light nor heavy --, costliest histogram bin first.
+    const int tiles_x = (wtiles_x + tw - 1) / tw, tiles_y = (wtiles_y + th - 1) / th, n_tiles = tiles_x * tiles_y;
+    auto tile_cost = [&](int t, bool &any) -> uint32_t {
+        const int tx = t % tiles_x, ty = t / tiles_x;
+        unsigned long long c = 0;
+        any = false;
+        for (int b = 0; b < th; b++)
+            for (int a = 0; a < tw; a++) {
+                const int wx = tx * tw + a, wy = ty * th + b;
+                if (wx >= wtiles_x || wy >= wtiles_y) continue;
+                const int i = wy * wtiles_x + wx;
+                if ((light && light[i]) || hidx[i] >= 0) continue;
+                any = true;
+                c += cost_in[i];
+            }
+        return c > 0xffffffffull ? 0xffffffffu : (uint32_t)c;
+    };
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t2 = threadIdx.x; t2 < n_tiles; t2 += 1024) {
+        bool any;
+        const uint32_t c = tile_cost(t2, any);
+        if (any) atomicAdd(&hist[bin_of(c)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned off = 0;
+        for (int b = 127; b >= 0; b--) {
+            const unsigned c = hist[b];
+            hist[b] = off;
+            off += c;
+        }
+        plan[3] = off;
+    }
+    __syncthreads();
+    for (int t2 = threadIdx.x; t2 < n_tiles; t2 += 1024) {
+        bool any;
+        const uint32_t c = tile_cost(t2, any);
+        if (any) border[atomicAdd(&hist[bin_of(c)], 1u)] = (uint32_t)t2;
     }
 }
 

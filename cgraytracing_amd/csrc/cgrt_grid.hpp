@@ -35,6 +35,11 @@ struct GridParams {
     const unsigned char *light;
     int32_t light_mode, pad_light_;
     const uint32_t *order;
+    // Tile queue of the scheduled launch (chunks == 1): border[0..plan[3]) = the tiles (ty * tiles_x + tx) with at least one
+    // wave tile that is neither heavy nor light, costliest first (plan_kernel); plan[4] = next entry.  The launch is then
+    // heavy_blocks + a chip's worth of workgroups, each serving one queue until it is empty and then the other, so neither
+    // empty tiles nor a late expensive tile cost anything at the end of the frame.  nullptr: one workgroup per tile.
+    const uint32_t *border;
     uint32_t *cost;
     const int32_t *hidx;
     uint32_t *plan;

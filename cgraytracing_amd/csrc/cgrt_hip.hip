@@ -323,7 +323,12 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         }
         d.light_ok = (planes_plain && special && !d.all_spheres) ? 1 : 0;
         if (d.light_ok && !s->aux_stream) {
-            if (hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+            // the light launch yields to the scheduled one: lowest stream priority
+            int prio_least = 0, prio_greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+            const char *pe = std::getenv("CGRT_AUX_PRIORITY");
+            const int prio = (pe && std::strcmp(pe, "same") == 0) ? 0 : (pe && std::strcmp(pe, "high") == 0) ? prio_greatest : prio_least;
+            if (hipStreamCreateWithPriority(&s->aux_stream, hipStreamNonBlocking, prio) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
                 d.light_ok = 0;  // no second stream: render everything with the full variant
@@ -547,7 +552,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const size_t sched_pad = 8;
     size_t sched_bytes = 0, defer_bytes = 0;
     if (reorder) {
-        sched_bytes = (3 * (n_wt + sched_pad) + 64) * sizeof(uint32_t) + ((n_wt + 255) & ~(size_t)255);  // cost, order, hidx, plan, light
+        sched_bytes = (4 * (n_wt + sched_pad) + 64) * sizeof(uint32_t) + ((n_wt + 255) & ~(size_t)255);  // cost, order, hidx, border, plan, light
         sched_bytes = (sched_bytes + 255) & ~(size_t)255;
         kmax = defer_budget / (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst);
         if (kmax > n_wt) kmax = n_wt;
@@ -581,6 +586,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.light_mode = 0;
     g.pad_light_ = 0;
     g.order = nullptr;
+    g.border = nullptr;
     g.cost = nullptr;
     g.hidx = nullptr;
     g.plan = nullptr;
@@ -638,8 +644,9 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         const size_t np = n_wt + sched_pad;
         uint32_t *cost = sb, *order = sb + np;
         int32_t *hidx = reinterpret_cast<int32_t *>(sb + 2 * np);
-        uint32_t *plan = sb + 3 * np;
-        unsigned char *light = reinterpret_cast<unsigned char *>(sb + 3 * np + 64);
+        uint32_t *border = sb + 3 * np;
+        uint32_t *plan = sb + 4 * np;
+        unsigned char *light = reinterpret_cast<unsigned char *>(sb + 4 * np + 64);
         unsigned char *dbase = base + sched_bytes;
         const bool split_light = s->dev.light_ok != 0 && g.chunks == 1 && !stats;
         if (split_light)
@@ -662,8 +669,14 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
         const int wave_slots = n_cu * 4 * (one_wave ? kBezWaves : (trees ? 3 : 4));
+        // tiles through a queue too (GridParams::border) unless their samples are split over workgroups or the workgroups are
+        // single waves (trace_grid_sched_kernel)
+        static const bool env_no_tile_queue = [] { const char *e = std::getenv("CGRT_NO_TILE_QUEUE"); return e && *e && *e != '0'; }();
+        const bool tile_queue = g.chunks == 1 && !one_wave && !env_no_tile_queue;
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, cost, split_light ? light : nullptr, (int)n_wt, (unsigned)kmax,
-                           (unsigned long long)wave_slots * (unsigned long long)heavy_div, plan, order, hidx);
+                           (unsigned long long)wave_slots * (unsigned long long)heavy_div, plan, order, hidx,
+                           tile_queue ? border : nullptr, wtiles_x, wtiles_y, one_wave ? 1 : kTileW / kWaveTileW,
+                           one_wave ? 1 : kTileH / kWaveTileH);
         if (split_light) g.light = light;
         g.order = order;
         g.hidx = hidx;
@@ -677,6 +690,10 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         const size_t fill = (size_t)wave_slots / waves_per_block;
         if (hb > fill) hb = fill;
         g.heavy_blocks = (int)hb;
+        if (tile_queue) {
+            g.border = border;
+            grid_dim = dim3((unsigned)fill);  // tile workgroups: a chip's worth, each loops over the tile queue
+        }
     }
     // development aid: CGRT_TIMELINE_FILE=path makes this launch synchronous and dumps, per workgroup, when and where it ran
     DevBuf timeline;
@@ -750,7 +767,7 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     g.half_width = cam->half_width; g.focus_plane = cam->focus_plane; g.lens_radius = cam->lens_radius;
     g.chunks = 1; g.chunk_spp = grid->spp; g.partial = nullptr; g.partial_nhit = nullptr;  // capture keeps one workgroup per tile
     g.timeline = nullptr;
-    g.light = nullptr; g.light_mode = 0; g.pad_light_ = 0; g.order = nullptr; g.cost = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
+    g.light = nullptr; g.light_mode = 0; g.pad_light_ = 0; g.order = nullptr; g.border = nullptr; g.cost = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
     g.probe = 0; g.heavy_blocks = 0; g.items_per_tile = 1; g.units_per_item = 256; g.maxhp = 16;
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_rec, b_cnt;

@@ -82,6 +82,13 @@ def main():
         "xcc_busy_us": {str(x): round(float(dur[xcc == x].sum()), 1) for x in sorted(set(xcc.tolist()))},
         "dur_weighted_by_rays_corr": round(float(np.corrcoef(dur, rays)[0, 1]), 3),
     }
+    idx = np.nonzero(ran)[0]
+    last = np.argsort(b)[::-1][:12]
+    doc["last_to_finish"] = [{"block": int(idx[i]), "start_us": round(float(a[i]), 1), "end_us": round(float(b[i]), 1), "rays": int(rays[i])}
+                             for i in last]
+    late = b > 0.8 * span
+    doc["finishing_in_last_fifth"] = {"workgroups": int(late.sum()), "mean_us": round(float(dur[late].mean()), 1) if late.any() else 0,
+                                      "started_after_half": int((late & (a > 0.5 * span)).sum())}
     half = 0.5 * max(conc)
     doc["fraction_of_span_below_half_peak_concurrency"] = round(sum(1 for c in conc if c < half) / bins, 2)
     print(json.dumps(doc, indent=1))
