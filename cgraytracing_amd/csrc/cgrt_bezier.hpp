@@ -106,7 +106,13 @@ struct NewtonState {
     V3 fv;          // F(res)
     int counter;
 };
-__device__ __forceinline__ double norm3(V3 v) { return sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+// The reference compares |F| = sqrt(x*x + y*y + z*z) with 1e-6 (carry on, bezier.h:171) and 1e-4 (accept, bezier.h:257).  With a
+// correctly rounded square root (the reference's sqrtsd) those comparisons are comparisons of the sum of squares with the largest
+// double whose root is <= 1e-6, resp. the smallest whose root is >= 1e-4 -- the same decisions without the root:
+//   sqrt(s) > 1e-6  <=>  s > 0x1.19799812dea11p-40        sqrt(s) < 1e-4  <=>  s < 0x1.5798ee2308c3ap-27
+// (tools/sqrt_thresholds.py derives and checks the two constants; NaN fails both forms, +inf passes the first in both).
+__device__ __forceinline__ double sumsq3(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+__device__ __forceinline__ bool newton_unconverged(V3 fv) { return sumsq3(fv) > 0x1.19799812dea11p-40; }
 
 __device__ __forceinline__ void newton_init(const BezierRec &b, V3 pos, V3 o, V3 d, double u0, double t0, NewtonState &st) {
     V3 pt = o + d * t0;
@@ -145,8 +151,9 @@ __device__ __forceinline__ bool newton_jacobian(const BezierRec &b, V3 d, Newton
         const double q0 = x * rc;
         return fma(fma(-dt, q0, x), rc, q0);
     };
-    const bool ordinary = fabs(n0) < 1e300 && fabs(n1) < 1e300 && fabs(n2) < 1e300 && fabs(n3) < 1e300 && fabs(n4) < 1e300 &&
-                          fabs(n5) < 1e300 && fabs(n6) < 1e300 && fabs(n7) < 1e300 && fabs(n8) < 1e300;
+    // largest magnitude among the numerators (fmax drops a NaN operand: a NaN numerator gives NaN through either form)
+    const bool ordinary = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))),
+                               fmax(fmax(fabs(n4), fabs(n5)), fmax(fmax(fabs(n6), fabs(n7)), fabs(n8)))) < 1e300;
     // The true divisions sit behind a WAVE-UNIFORM branch: written as a per-quotient select, the compiler evaluated
     // both forms for every quotient (nine ~13-instruction divisions per Newton iteration, a quarter of the loop).
     if (__ballot(!ordinary) == 0ull) {
@@ -169,7 +176,7 @@ __device__ __forceinline__ void newton_step(const BezierRec &b, V3 pos, V3 o, V3
     st.fv = ((o + d * st.res.x) - pos) - mk(st.P.z * st.sn, st.P.y, st.P.z * st.cs);
 }
 __device__ __forceinline__ bool newton_accept(const NewtonState &st) {  // bezier.h:257
-    return norm3(st.fv) < 1e-4 && st.res.x > 0 && st.res.y <= 1 && st.res.y >= 0;
+    return sumsq3(st.fv) < 0x1.5798ee2308c3ap-27 && st.res.x > 0 && st.res.y <= 1 && st.res.y >= 0;
 }
 __device__ __forceinline__ V3 bez_normal(const BezierRec &b, double u, double sn, double cs) {  // bezier.h:215-224
     const V3 rp = normalized(bez_grad(b, u));
@@ -186,7 +193,7 @@ __device__ bool bezier_solve_serial(const BezierRec &b, V3 pos, V3 o, V3 d, Stre
         const double t0 = 20 + 10 * rs.u01();
         NewtonState st;
         newton_init(b, pos, o, d, u0, t0, st);
-        while (norm3(st.fv) > 1e-6 && st.counter < 100) {
+        while (newton_unconverged(st.fv) && st.counter < 100) {
             st.counter++;
             if (!newton_jacobian(b, d, st)) {
                 // bezier.h:183: Vec3(u(),u(),u()) evaluates right to left under g++
@@ -284,7 +291,7 @@ __device__ bool bezier_wave(const BezierRec &b, V3 pos, double cap_r, bool on, V
             }
             if (__ballot(busy) == 0ull) break;
             if (busy) {
-                if (norm3(st.fv) > 1e-6 && st.counter < 100) {
+                if (newton_unconverged(st.fv) && st.counter < 100) {
                     st.counter++;
                     if (newton_jacobian(b, sd, st)) {
                         newton_step(b, pos, so, sd, st);
