@@ -232,8 +232,12 @@ struct BezLds {
 // `n0`: position of the ray's first draw in the stream `key` (0 for the eye pass, whose Bezier streams are keyed per ray;
 // the photon pass continues the photon's own sequential stream, as the reference's rand() does).  On return `n0` has
 // advanced by the draws the reference would have consumed (0 when the ray misses the box).
-__device__ bool bezier_wave(const BezierRec &b, V3 pos, double cap_r, bool on, V3 o, V3 d, uint64_t key, uint32_t &n0,
+__device__ bool bezier_wave(const BezierRec &b_in, V3 pos, double cap_r, bool on, V3 o, V3 d, uint64_t key, uint32_t &n0,
                             double &len, V3 &n, volatile BezLds *L) {
+    // the record sits at a wave-uniform address: through the constant address space its control points live in SGPRs for
+    // the whole solve instead of being re-fetched per lane in every Bernstein sum (the LDS traffic of the loop keeps the
+    // compiler from hoisting ordinary loads)
+    const BezierRec b = load_uniform(&b_in);
     const int lane = threadIdx.x & 63;
     const bool want = on && bez_box(b, o, d);
     const unsigned long long wm = __ballot(want);
