@@ -665,6 +665,28 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
             gp.light_mode = 0;
         }
         launch(gp, dim3((unsigned)tile_blocks), nullptr, nullptr, nullptr);
+        if (split_light) {
+            // The light tiles: the variant without tree / Bezier / pending-ray code on the second stream, beside everything that
+            // follows here.  It needs nothing but the classification and starts as soon as the probe is through, beside the
+            // plan (one workgroup, 0.1-0.3 ms).  Started before the probe it perturbs the measured costs and delays the
+            // probe's workgroups: C3 14.4 -> 14.1 ms but C4 (spp 64) 33.6 -> 35.3 ms.
+            GridParams gl = g;
+            gl.light = light;
+            gl.light_mode = 1;
+            gl.timeline = nullptr;
+            HIP_TRY(hipEventRecord(s->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
+            const size_t lds_light = (size_t)s->dev.n_objs * sizeof(ObjRec);
+            const dim3 gd_light((unsigned)tile_grid_blocks(g.W, g.rows, false));
+            gl.xcd_tiles = 0;
+            if (dof)
+                hipLaunchKernelGGL((trace_grid_kernel<false, false, true, false, false, false>), gd_light, dim3(kThreads), lds_light,
+                                   s->aux_stream, s->dev, gl, rgb, nhit, cnt);
+            else
+                hipLaunchKernelGGL((trace_grid_kernel<false, false, false, false, false, false>), gd_light, dim3(kThreads), lds_light,
+                                   s->aux_stream, s->dev, gl, rgb, nhit, cnt);
+            HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
+        }
         // heavy: cost x spp > (total cost x spp / wave slots) / heavy_div
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
@@ -702,26 +724,6 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         HIP_TRY(timeline.alloc(((size_t)grid_dim.x + g.heavy_blocks) * 32));
         HIP_TRY(hipMemsetAsync(timeline.p, 0, ((size_t)grid_dim.x + g.heavy_blocks) * 32, st));
         g.timeline = timeline.as<unsigned long long>();
-    }
-    if (g.light) {
-        // the light tiles: the variant without tree / Bezier / pending-ray code on the second stream, beside the full launch
-        GridParams gl = g;
-        gl.light_mode = 1;
-        gl.hidx = nullptr;  // light tiles are never heavy
-        gl.heavy_blocks = 0;
-        gl.timeline = nullptr;
-        HIP_TRY(hipEventRecord(s->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
-        const size_t lds_light = (size_t)s->dev.n_objs * sizeof(ObjRec);
-        const dim3 gd_light((unsigned)tile_grid_blocks(g.W, g.rows, false));
-        gl.xcd_tiles = 0;
-        if (dof)
-            hipLaunchKernelGGL((trace_grid_kernel<false, false, true, false, false, false>), gd_light, dim3(kThreads), lds_light,
-                               s->aux_stream, s->dev, gl, rgb, nhit, cnt);
-        else
-            hipLaunchKernelGGL((trace_grid_kernel<false, false, false, false, false, false>), gd_light, dim3(kThreads), lds_light,
-                               s->aux_stream, s->dev, gl, rgb, nhit, cnt);
-        HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
     }
     if (g.heavy_blocks > 0) {  // heavy workgroups in front, the tile workgroups behind them, one launch
         hipLaunchKernelGGL(pixel_const_kernel, dim3((unsigned)kmax), dim3(64), 0, st, g);
