@@ -88,6 +88,7 @@ SIGNATURES = {
                                      C.c_void_p]),
     "cgrt_scene_bvh_dump": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "cgrt_scene_bvh_order": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p]),
+    "cgrt_scene_wide_dump": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "cgrt_lens_samples": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "cgrt_surface_colors": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "cgrt_trace_grid_variant": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_char_p, C.c_size_t]),

@@ -257,6 +257,7 @@ struct BvhBuilder {
     std::vector<int32_t> idx;
     std::vector<BvhTmp> nodes;          // preallocated (2 * items); slots are claimed through `next`, so node NUMBERS depend on
     std::atomic<int32_t> next{0};       // thread timing -- the tree's shape, and everything emitted from it, does not
+    int sah_depth = 48;   // binned SAH down to this depth, object-median splits (balanced) below
     size_t max_leaf = 1;  // 1: one item (a reference leaf) per leaf, leafref = the item's; > 1: items are triangles and
                           // a leaf is a run of idx, leafref = (first position << 4) | count
 
@@ -288,7 +289,7 @@ struct BvhBuilder {
         constexpr int NB = 16;
         int best_axis = -1, best_bin = -1;
         double best_cost = 1e300;
-        for (int ax = 0; ax < 3 && depth < 48; ax++) {
+        for (int ax = 0; ax < 3 && depth < sah_depth; ax++) {
             const double ext = chi[ax] - clo[ax];
             if (!(ext > 0)) continue;
             double blo[NB][3], bhi[NB][3];
@@ -369,6 +370,54 @@ struct BvhBuilder {
         m.left_is_lower = (L.lo[axis] + L.hi[axis]) <= (R.lo[axis] + R.hi[axis]);
         return me;
     }
+    // The 4-wide form (WideNodeRec): a node's children are its two binary children, the larger-surfaced inner one of which is
+    // replaced by ITS children until there are four or only leaves.  Returns the wide node's index; `need` = how deep the
+    // walk's stack can get below it (descending into one child leaves at most the others waiting).
+    int32_t emit_wide(int32_t n, std::vector<WideNodeRec> &out, int32_t &need) const {
+        int32_t kids[4], nk = 0;
+        if (nodes[(size_t)n].leafref >= 0) {
+            kids[nk++] = n;  // a tree that is one leaf: a root with that one child
+        } else {
+            kids[nk++] = nodes[(size_t)n].left;
+            kids[nk++] = nodes[(size_t)n].right;
+            while (nk < 4) {
+                int best = -1;
+                double best_area = -1;
+                for (int k = 0; k < nk; k++) {
+                    const BvhTmp &c = nodes[(size_t)kids[k]];
+                    if (c.leafref >= 0) continue;
+                    const double a = half_area(c.lo, c.hi);
+                    if (a > best_area) { best_area = a; best = k; }
+                }
+                if (best < 0) break;
+                const BvhTmp &c = nodes[(size_t)kids[best]];
+                kids[best] = c.left;
+                kids[nk++] = c.right;
+            }
+        }
+        const int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        WideNodeRec w;
+        std::memset(&w, 0, sizeof(w));
+        need = 0;
+        for (int k = 0; k < 4; k++) {
+            if (k >= nk) { w.ref[k] = kWideNone; continue; }
+            const BvhTmp &c = nodes[(size_t)kids[k]];
+            w.lox[k] = round_down(c.lo[0] - kBoxPad); w.loy[k] = round_down(c.lo[1] - kBoxPad); w.loz[k] = round_down(c.lo[2] - kBoxPad);
+            w.hix[k] = round_up(c.hi[0] + kBoxPad);   w.hiy[k] = round_up(c.hi[1] + kBoxPad);   w.hiz[k] = round_up(c.hi[2] + kBoxPad);
+            if (c.leafref >= 0) {
+                w.ref[k] = c.leafref;
+                need = std::max(need, nk - 1);
+            } else {
+                int32_t below = 0;
+                const int32_t child = emit_wide(kids[k], out, below);
+                w.ref[k] = ~child;
+                need = std::max(need, nk - 1 + below);
+            }
+        }
+        out[(size_t)me] = w;
+        return me;
+    }
     // preorder with skip links into out[0..): `cur` is the next free slot of this octant's array
     void emit(int32_t n, int oct, NodeRec *out, int32_t &cur) const {
         const BvhTmp &t = nodes[(size_t)n];
@@ -431,9 +480,24 @@ void HostTree::build_bvh(bool opaque) {
     }
     if (B.items.empty()) return;
     B.idx.resize(B.items.size());
-    for (size_t i = 0; i < B.idx.size(); i++) B.idx[i] = (int32_t)i;
     B.nodes.resize(2 * B.items.size());
-    const int32_t root = B.build(0, B.items.size(), 0);
+    wide.clear();
+    wide_stack = 0;
+    int32_t root = 0;
+    // An opaque owner's hierarchy is walked in its 4-wide form with a stack of kWideStack entries.  SAH splits can chain
+    // (a long sliver next to many small triangles peels one item per level); if the stack bound is missed the build is
+    // repeated with SAH confined to the top levels -- object-median splits below are balanced, and with none at all the
+    // bound is 1.5 log2(n) < 48.
+    for (int cap : {48, 8, 0}) {
+        for (size_t i = 0; i < B.idx.size(); i++) B.idx[i] = (int32_t)i;
+        B.next.store(0);
+        B.sah_depth = cap;
+        root = B.build(0, B.items.size(), 0);
+        if (!opaque) break;
+        wide.clear();
+        B.emit_wide(root, wide, wide_stack);
+        if (wide_stack < kWideStack) break;
+    }
     bvh_nodes = B.next.load();
     bvh.resize((size_t)bvh_nodes * 8);
     {  // the eight layouts are independent: one thread each

@@ -31,6 +31,8 @@ struct HostTree {
     // TRIANGLES (<= 4) instead of stopping at the reference's leaves; its leaves index otris
     bool tri_level = false;
     std::vector<OTriRec> otris;
+    std::vector<WideNodeRec> wide;  // tri_level: the same hierarchy four children to a node (device walk); root = wide[0]
+    int32_t wide_stack = 0;         // deepest the walk's stack can get on it (< kWideStack, or `wide` is left empty)
     void build_bvh(bool opaque);
     // bump floors only: the same triangles in grid order (construction order is cell-major: quad (i,j) = triangles
     // 2*(i*nx+j) and +1), see HCellRec

@@ -48,6 +48,10 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
     // TREES: node cache behind that (32-byte records, region is 16-byte aligned)
     NodeRec *lnodes = reinterpret_cast<NodeRec *>(lrest);
     aux.lnodes = (TREES && sc.cached_tree >= 0) ? lnodes : nullptr;
+    // TREES without glass or Bezier (their LDS is spoken for): the first entries of the wide walk's stack, behind the node cache
+    aux.wstack = (TREES && !GLASS && !BEZ && sc.has_wide)
+                     ? reinterpret_cast<uint2 *>(lrest + ((sc.cached_tree >= 0 ? (size_t)sc.cached_nodes * sizeof(NodeRec) : 0)))
+                     : nullptr;
     if (TREES && sc.cached_tree >= 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes + sc.trees[sc.cached_tree].node_begin);
         uint4 *dst = reinterpret_cast<uint4 *>(lnodes);

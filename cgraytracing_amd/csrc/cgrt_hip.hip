@@ -220,6 +220,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     std::vector<HCellRec> hcells;
     std::vector<OTriRec> otris;
     std::vector<NodeRec> tboxes;
+    std::vector<WideNodeRec> wnodes;
     for (auto &t : H.trees) {
         TreeRec tr;
         tr.node_begin = (int64_t)nodes.size();
@@ -244,8 +245,17 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
             hcells.insert(hcells.end(), t.hcells.begin(), t.hcells.end());
         }
         tr.tbox_begin = (int64_t)tboxes.size();
+        tr.wnode_begin = (int64_t)wnodes.size();
+        tr.nwide = tr.tri_level ? (int32_t)t.wide.size() : 0;
+        tr.pad2 = 0;
+        if (tr.nwide > 0) wnodes.insert(wnodes.end(), t.wide.begin(), t.wide.end());
         tboxes.insert(tboxes.end(), t.tboxes.begin(), t.tboxes.end());
-        nodes.insert(nodes.end(), dev_nodes.begin(), dev_nodes.end());
+        if (tr.nwide > 0) {  // the device walks the wide form: the one-box-per-node copies stay on the host (cgrt_scene_bvh_dump)
+            tr.nnodes = 0;
+            tr.noct = 1;
+        } else {
+            nodes.insert(nodes.end(), dev_nodes.begin(), dev_nodes.end());
+        }
         tris.insert(tris.end(), t.tris.begin(), t.tris.end());
         trees.push_back(tr);
     }
@@ -282,6 +292,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         if ((rc = upload(s, hcells, &d.hcells))) return rc;
         if ((rc = upload(s, otris, &d.otris))) return rc;
         if ((rc = upload(s, tboxes, &d.tboxes))) return rc;
+        if ((rc = upload(s, wnodes, &d.wnodes))) return rc;
         if ((rc = upload(s, H.cover, &d.cover))) return rc;
         return CGRT_OK;
     };
@@ -297,6 +308,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     d.n_texs = (int32_t)texs.size();
     d.n_beziers = (int32_t)H.beziers.size();
     d.n_cover = (int32_t)(H.cover.size() / 4);
+    d.has_wide = wnodes.empty() ? 0 : 1;
     d.has_mesh = trees.empty() ? 0 : 1;
     d.has_bezier = H.beziers.empty() ? 0 : 1;
     d.cached_tree = -1;
@@ -387,6 +399,24 @@ int cgrt_scene_bvh_dump(const cgrt_scene *s, int t, int32_t *nnodes, float *box6
         if (skip_leaf2) {
             skip_leaf2[2 * i] = T.bvh[i].skip;
             skip_leaf2[2 * i + 1] = T.bvh[i].leaf;
+        }
+    }
+    return CGRT_OK;
+}
+int cgrt_scene_wide_dump(const cgrt_scene *s, int t, int32_t *nwide, int32_t *stack_need, float *box24, int32_t *ref4) {
+    if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
+    const HostTree &T = s->host.trees[t];
+    if (nwide) *nwide = (int32_t)T.wide.size();
+    if (stack_need) *stack_need = T.wide_stack;
+    for (size_t i = 0; i < T.wide.size(); i++) {
+        const WideNodeRec &w = T.wide[i];
+        for (int k = 0; k < 4; k++) {
+            if (box24) {
+                float *q = box24 + (4 * i + (size_t)k) * 6;
+                q[0] = w.lox[k]; q[1] = w.loy[k]; q[2] = w.loz[k];
+                q[3] = w.hix[k]; q[4] = w.hiy[k]; q[5] = w.hiz[k];
+            }
+            if (ref4) ref4[4 * i + (size_t)k] = w.ref[k];
         }
     }
     return CGRT_OK;
@@ -601,6 +631,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     if (one_wave) lds += (glass ? TileGeom<64>::stack_bytes : 0) + sizeof(BezLds);
     else lds += glass ? kStackBytes : 0;
     if (trees && s->dev.cached_tree >= 0) lds += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
+    if (trees && !glass && !bez && s->dev.has_wide) lds += (size_t)kThreads * kWideLdsDepth * sizeof(uint2);  // wide walk's stack
     static const int env_lds_pad = [] { const char *e = std::getenv("CGRT_LDS_PAD"); return e ? std::atoi(e) : 0; }();
     lds += (size_t)env_lds_pad;
     auto launch_mode = [&](auto sched_tag, const GridParams &gp, dim3 gd, float *rgb_, uint32_t *nhit_, unsigned long long *cnt_) {

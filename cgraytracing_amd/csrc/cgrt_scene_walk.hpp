@@ -82,6 +82,7 @@ static constexpr int kNodeCache = 256;  // 8 KiB of 32-byte nodes
 struct LdsAux {
     volatile BezLds *bl;    // this wave's Bezier scratch (BEZ variants) or nullptr
     const NodeRec *lnodes;  // LDS copy of tree sc.cached_tree's nodes, or nullptr
+    uint2 *wstack = nullptr;  // LDS part of the 4-wide walk's stack ([entry][thread]), or nullptr
 };
 
 // tree traversal entry; `on` = this lane really has a ray for this tree (all lanes of the wave call it).
@@ -109,17 +110,17 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     const NodeRec *nodes = sc.nodes + T.node_begin + (size_t)oct * (size_t)T.nnodes;
     const TriRec *tris = sc.tris + T.tri_begin;
     if (opaque) {
-        if (T.tri_level) {
-            const OTriRec *ot = sc.otris + T.otri_begin;
-            if (cached) return tree_intersect<STATS, true, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, ot);
-            return tree_intersect<STATS, true, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, ot);
+        if (T.tri_level) {  // an opaque mesh: the 4-wide triangle-level hierarchy (an empty mesh has no nodes at all)
+            if (T.nwide == 0) return none;
+            return tree_intersect_wide<STATS>(sc.wnodes + T.wnode_begin, sc.otris + T.otri_begin, o, d, inv, bound, n_node, n_tri,
+                                              aux.wstack);
         }
         if (cached) return tree_intersect<STATS, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
         return tree_intersect<STATS, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
     }
     const NodeRec *tb = sc.tboxes + T.tbox_begin;
-    if (cached) return tree_intersect<STATS, false>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, nullptr, tb);
-    return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, nullptr, tb);
+    if (cached) return tree_intersect<STATS, false>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, tb);
+    return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, tb);
 }
 
 template <bool TREES, bool BEZ, bool SPH, bool STATS>
@@ -190,9 +191,9 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
         } else if (TREES && kind == KIND_MESH) {
             // TriangleMesh::intersect, objects.h:405-455
             const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
-            // Early-out without a division: a ray whose LINE misses the sphere around the mesh (ObjRec.a, s0; it contains the
-            // root box and its 1e-4 slack), or that points away from it from outside, cannot touch any node -- the reference
-            // would reject it at the root (objects.h:270-271).  Most waves of a frame never come near the mesh and skip the
+            // Early-out without a division: a ray whose LINE misses the sphere around the mesh's vertices (ObjRec.a, s0, with
+            // 1e-3 to spare), or that points away from it from outside, cannot hit a triangle, whatever boxes it crosses: the
+            // tree would return nothing that counts.  Most waves of a frame never come near the mesh and skip the
             // tree call, its three divisions and its root fetch altogether (measured: 7.7 of C4's 42.7 ms at spp 64).
             const V3 lc = ld3(ob.a) - o;
             const double tca = dot(lc, d), l2 = dot(lc, lc), dd = dot(d, d), r2 = ob.s0;

@@ -65,6 +65,21 @@ struct OTriRec {
 };
 static_assert(sizeof(OTriRec) == 80, "OTriRec layout");
 
+// Opaque meshes: node of the 4-wide form of the triangle-level hierarchy -- the boxes of up to four children, one coordinate
+// of all four per 16-byte load, so that one fetch round (seven independent loads of one 128-byte line) decides four boxes
+// and the walk needs ~2.5x fewer DEPENDENT fetches than with one box per node.  ref: >= 0 a leaf ((first otri << 4) | count),
+// kWideNone an empty slot, otherwise ~(index of the child node, relative to the tree's first wide node).  Boxes are grown
+// and rounded outward exactly like NodeRec's.
+struct WideNodeRec {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int32_t ref[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(WideNodeRec) == 128, "WideNodeRec layout");
+static constexpr int32_t kWideNone = INT32_MIN;
+static constexpr int kWideLdsDepth = 16;  // of them in LDS where the workgroup has room (8 bytes per entry and thread)
+static constexpr int kWideStack = 64;  // entries of the walk's per-lane stack; cgrt_build.cpp guarantees a tree needs fewer
+
 struct TreeRec {
     int64_t node_begin;  // into nodes[]
     int64_t tri_begin;   // into tris[]
@@ -78,6 +93,9 @@ struct TreeRec {
                          // reference's leaves, leaves index tris[]
     int32_t pad;
     int64_t tbox_begin;  // into tboxes[]: one box per triangle of tris[], same order
+    int64_t wnode_begin; // tri_level only: into wnodes[] (nwide records, root first); nwide == 0: walk nodes[] instead
+    int32_t nwide;
+    int32_t pad2;
 };
 
 // A bump-mapped floor's displacement mesh (objects.h:482-503) is a height field over a regular x-z grid: one quad per
@@ -129,6 +147,7 @@ struct DeviceScene {
     const HCellRec *hcells;
     const OTriRec *otris;
     const NodeRec *tboxes;
+    const WideNodeRec *wnodes;
     const double *cover;  // n_cover x (cx, cy, cz, r): spheres that together contain every mesh triangle
     int32_t n_objs, n_trees, n_texs, n_beziers;
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
@@ -137,6 +156,7 @@ struct DeviceScene {
     int32_t has_glass;   // some object takes the refraction branch (main.cpp:135)
     int32_t cached_tree; // tree whose nodes every workgroup stages in LDS (-1: none)
     int32_t cached_nodes;
+    int32_t has_wide;    // some tree is walked in its 4-wide form (the eye kernels' LDS stack)
     int32_t light_ok;    // every plane is diffuse and un-bumped and some object is "special" (mesh, Bezier, mirror or glass
                          // sphere): tiles whose primary rays provably stay clear of the special objects' bounding spheres see
                          // diffuse spheres and planes only and may be rendered by the light kernel variant (cgrt_hip.hip)

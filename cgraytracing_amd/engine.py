@@ -122,6 +122,15 @@ class Scene:
         check(self._L.cgrt_scene_bvh_order(self._h, t, C.byref(lvl), order.ctypes.data))
         return bool(lvl.value), order[: nt.value]
 
+    def wide_dump(self, t=0):
+        """(box[nwide, 4, 6], ref[nwide, 4], stack_need): see cgrt_scene_wide_dump."""
+        n, need = C.c_int32(), C.c_int32()
+        check(self._L.cgrt_scene_wide_dump(self._h, t, C.byref(n), C.byref(need), None, None))
+        box = np.zeros((max(n.value, 1), 4, 6), np.float32)
+        ref = np.zeros((max(n.value, 1), 4), np.int32)
+        check(self._L.cgrt_scene_wide_dump(self._h, t, C.byref(n), C.byref(need), box.ctypes.data, ref.ctypes.data))
+        return box[: n.value], ref[: n.value], need.value
+
     # ---- the hot path ----
     def _structs(self, camera, width, height, rows, spp, max_depth, seed, row_offset, stripe, sample_offset,
                  spp_total, flags):

@@ -29,8 +29,8 @@
 extern "C" {
 #endif
 
-#define CGRT_VERSION 110 /* 0.1.1: cgrt_photons.initial_radius / .pair_cap, cgrt_ppm_result.n_batch_halvings,
-                            cgrt_surface_colors, cgrt_trace_grid_variant */
+#define CGRT_VERSION 111 /* 110: cgrt_photons.initial_radius / .pair_cap, cgrt_ppm_result.n_batch_halvings,
+                            cgrt_surface_colors, cgrt_trace_grid_variant; 111: cgrt_scene_wide_dump */
 
 enum {
     CGRT_OK = 0,
@@ -171,6 +171,11 @@ int cgrt_scene_bvh_dump(const cgrt_scene *s, int tree, int32_t *nnodes, float *b
  * cgrt_scene_bvh_dump then index the hierarchy's own triangle order, and order[j] (ntris entries, may be NULL) is the
  * leaf-order index of the triangle at position j; 0: leaf references index the reference's leaf order directly. */
 int cgrt_scene_bvh_order(const cgrt_scene *s, int tree, int32_t *tri_level, int32_t *order);
+/* The 4-wide form of a triangle-level hierarchy (what the device walks for an opaque owner; *nwide = 0 for other trees):
+ * node i has up to four children, box24[(4*i + k)*6 ..] = lo[3], hi[3] of child k and ref4[4*i + k] = its reference --
+ * >= 0 a leaf ((first triangle of the hierarchy's order << 4) | count), INT32_MIN an empty slot, otherwise ~(child node).
+ * *stack_need = the deepest the walk's stack can get (always below 64).  Two-call protocol: box24 / ref4 may be NULL. */
+int cgrt_scene_wide_dump(const cgrt_scene *s, int tree, int32_t *nwide, int32_t *stack_need, float *box24, int32_t *ref4);
 
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Renders grid->rows rows: for every pixel and sample it runs the reference's trace(flag=true) recursion

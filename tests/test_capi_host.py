@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libcgrt.so does not export %s" % name
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
-    assert _capi.lib().cgrt_version() == 110
+    assert _capi.lib().cgrt_version() == 111
 
 
 def test_struct_layouts_match_header():
@@ -275,6 +275,46 @@ def _check_hierarchy(sc, t):
                 assert ((cb - ca) * sgn >= 0).any()
 
 
+def _check_wide(sc, t):
+    """The 4-wide form the device walks for an opaque owner: a tree over node 0 in which every node is referenced exactly
+    once; its leaves are exactly the leaves of the one-box-per-node form, each once, with that form's (grown, outward-rounded)
+    box; an inner reference carries the box of the node it stands for = the union of that node's child boxes; the stack bound
+    holds (children - 1 summed along any root-to-leaf path)."""
+    box, ref, need = sc.wide_dump(t)
+    tri_level, _ = sc.bvh_order(t)
+    if not tri_level:
+        assert len(ref) == 0
+        return
+    bbox, bskip, bleaf = sc.bvh_dump(t)
+    want = {int(v): bbox[0][i] for i, v in enumerate(bleaf[0]) if v >= 0}
+    NONE = -2 ** 31
+    seen_nodes, seen_leaves = set(), {}
+    worst = 0
+    stack = [(0, 0)]
+    while stack:
+        i, pending = stack.pop()
+        assert i not in seen_nodes
+        seen_nodes.add(i)
+        kids = [k for k in range(4) if ref[i, k] != NONE]
+        assert kids == list(range(len(kids))) and len(kids) >= 1
+        for k in kids:
+            r = int(ref[i, k])
+            if r >= 0:
+                assert r not in seen_leaves
+                seen_leaves[r] = box[i, k]
+                worst = max(worst, pending + len(kids) - 1)
+            else:
+                c = ~r
+                ck = [q for q in range(4) if ref[c, q] != NONE]
+                assert (box[c, ck, :3].min(0) == box[i, k, :3]).all() and (box[c, ck, 3:].max(0) == box[i, k, 3:]).all()
+                stack.append((c, pending + len(kids) - 1))
+    assert seen_nodes == set(range(len(ref)))
+    assert set(seen_leaves) == set(want)
+    for r, b in seen_leaves.items():
+        assert (b == want[r]).all()
+    assert worst == need < 64
+
+
 def _ref_leaf_runs(nodes):
     """(first index in leaf order, count) of the reference's non-empty leaves, in node order."""
     runs, first = [], 0
@@ -295,6 +335,7 @@ def test_device_hierarchy_structure():
         sc = Scene([scenes.TriangleMesh(path, 2.5, (-3.0, -6.0, 28.0), (0.6, 0.7, 0.9), 0.8, transp, 1)], commit=False)
         assert sc.bvh_order(0)[0] == (transp == 0.0)
         _check_hierarchy(sc, 0)
+        _check_wide(sc, 0)
         sc.close()
     sc = Scene(scenes.scene_c3(True), commit=False)
     _check_hierarchy(sc, 0)
@@ -302,6 +343,16 @@ def test_device_hierarchy_structure():
     sc = Scene([scenes.TriangleMesh.from_triangles(scenes.procedural_mesh(40, 30, (-5.0, -10.0, 30.0), 9.0), (0.25, 0.25, 0.5), 0.0, 0.0, 1)],
                commit=False)
     _check_hierarchy(sc, 0)
+    _check_wide(sc, 0)
+    sc.close()
+    # geometrically growing triangles: binned SAH peels the largest few off per level -- a chain hundreds of levels deep,
+    # beyond the wide walk's stack; the build must fall back to shallower (median) splits and still meet the bound
+    k = np.arange(400, dtype=np.float64)
+    s = 1e-3 * 1.15 ** k
+    chain = np.stack([np.stack([s, 0 * s, 30 + 0 * s], 1), np.stack([2 * s, 0 * s, 30 + 0 * s], 1), np.stack([s, s, 30 + 0 * s], 1)], 1)
+    sc = Scene([scenes.TriangleMesh.from_triangles(chain, (0.5, 0.5, 0.5), 0.0, 0.0)], commit=False)
+    _check_hierarchy(sc, 0)
+    _check_wide(sc, 0)
     sc.close()
     floor = scenes.Plane((0.0, -20, 0), (0, 1, 0), (0.15, 0.15, 0.15), 0.8, 0.5, scenes.stone_small_texture(True))
     sc = Scene([floor], commit=False)
