@@ -651,3 +651,40 @@ def test_light_tiles_around_a_long_thin_mesh(gpu_ready, orc, kind, lens):
         assert got["nrays"] == want["nrays"] and np.array_equal(got["nhit"], want["nhit"])
         assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
 
+
+@pytest.mark.parametrize("refl,lens", [(0.8, False), (0.8, True)])
+def test_wide_walk_with_a_deep_stack(gpu_ready, orc, refl, lens):
+    """The 4-wide walk of opaque meshes keeps the first 16 stack entries in LDS and the rest in scratch.
+    100 000 large thin triangles stacked along the view axis, each cut so that it just misses the axis: a central ray touches every
+    box of the hierarchy and hits nothing, so at each of the ~8 levels of the descent three siblings stay pending (19-20 entries
+    by the first leaf) and every one of them is taken up again; rays off the axis hit one of the first few triangles -- often not in the
+    first leaf but in a sibling waiting at the deep end of the stack -- and are reflected, by these tilted mirrors, to whichever
+    wall the triangle's normal points at.  Image, hit counts and ray count equal the oracle's, scheduled and in image order.
+    (Checked by dropping the entries beyond the LDS part: 277 / 519 pixels of these two frames change; with 20 000 triangles
+    the stack stops at 16 by the first leaf and nothing would.)"""
+    import cgraytracing_amd as cg
+    rng = np.random.default_rng(4242)
+    n = 100000
+    z = np.sort(rng.uniform(5.0, 38.0, n))
+    flip = rng.integers(0, 4, n)
+    a = np.stack([np.full(n, -2.0), np.full(n, -2.0), z], 1)
+    b = np.stack([np.full(n, 2.0), np.full(n, -2.0), z + rng.uniform(-0.4, 0.4, n)], 1)  # tilted: as mirrors they send the ray
+    c = np.stack([np.full(n, -2.0), 1.9 - rng.uniform(0, 0.05, n), z + rng.uniform(-0.4, 0.4, n)], 1)  # to differently coloured walls
+    tri = np.stack([a, b, c], 1)
+    for k in range(1, 4):  # the cut corner in any of the four quadrants
+        m = flip == k
+        if k & 1:
+            tri[m, :, 0] *= -1
+        if k & 2:
+            tri[m, :, 1] *= -1
+    objs = scenes.planes() + [scenes.TriangleMesh.from_triangles(tri, (0.7, 0.8, 0.9), refl, 0.0)]
+    cam = scenes.cam_dof() if lens else scenes.cam_pinhole()
+    W, H, spp = 256, 192, 4
+    want = BackendScene(orc, objs).trace_grid(cam, W, H, spp, 5, seed=5)
+    with cg.Scene(objs) as sc:
+        assert sc.wide_dump(0)[2] > 16  # the host's bound on the stack depth: this tree can need more than the LDS part
+        got = sc.trace_grid_host(W, H, spp, cam, 5, 5)
+        nat = sc.trace_grid_host(W, H, spp, cam, 5, 5, reorder=False)
+    assert np.array_equal(got["rgb"], nat["rgb"]) and np.array_equal(got["nhit"], nat["nhit"]) and got["nrays"] == nat["nrays"]
+    assert got["nrays"] == want["nrays"] and np.array_equal(got["nhit"], want["nhit"])
+    assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
