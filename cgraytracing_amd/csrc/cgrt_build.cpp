@@ -784,6 +784,51 @@ int HostScene::add_bezier(const double *cp3, int ncp, const double pos[3], const
     b.box[4] = -max_z + pos[2];
     b.box[5] = max_z + pos[2];
     o.b[0] = b.cp[ncp - 1][2];  // radius of the cap disc (bezier.h:277)
+    // bounds of the surface piece by piece (BezSlabRec): the control points of the curve restricted to [u0, u1] by two de
+    // Casteljau subdivisions; a Bezier curve lies in the hull of its control points
+    for (int k = 0; k < kBezSlabs; k++) {
+        const double u0 = (double)k / kBezSlabs, u1 = (double)(k + 1) / kBezSlabs;
+        double q[6][3];
+        for (int i = 0; i < ncp; i++)
+            for (int c = 0; c < 3; c++) q[i][c] = b.cp[i][c];
+        auto split_left = [&](double t) {  // q := control points of the part [0, t]
+            double w[6][3], out[6][3];
+            std::memcpy(w, q, sizeof(w));
+            for (int lvl = 0; lvl < ncp; lvl++) {
+                for (int c = 0; c < 3; c++) out[lvl][c] = w[0][c];
+                for (int i = 0; i + 1 < ncp - lvl; i++)
+                    for (int c = 0; c < 3; c++) w[i][c] = (1 - t) * w[i][c] + t * w[i + 1][c];
+            }
+            std::memcpy(q, out, sizeof(out));
+        };
+        auto split_right = [&](double t) {  // q := control points of the part [t, 1]
+            double w[6][3], out[6][3];
+            std::memcpy(w, q, sizeof(w));
+            for (int lvl = 0; lvl < ncp; lvl++) {
+                for (int c = 0; c < 3; c++) out[ncp - 1 - lvl][c] = w[ncp - 1 - lvl][c];
+                for (int i = 0; i + 1 < ncp - lvl; i++)
+                    for (int c = 0; c < 3; c++) w[i][c] = (1 - t) * w[i][c] + t * w[i + 1][c];
+            }
+            std::memcpy(q, out, sizeof(out));
+        };
+        split_left(u1);
+        if (u0 > 0) split_right(u0 / u1);
+        BezSlabRec sl;
+        sl.ylo = kInf; sl.yhi = -kInf;
+        double rmax = 0;
+        for (int i = 0; i < ncp; i++) {
+            sl.ylo = std::min(sl.ylo, q[i][1]);
+            sl.yhi = std::max(sl.yhi, q[i][1]);
+            rmax = std::max(rmax, std::fabs(q[i][2]));
+        }
+        const double span = std::max(1.0, std::max(rmax, std::max(std::fabs(sl.ylo), std::fabs(sl.yhi))));
+        const double grow = 1e-3 * span;  // far above the 1e-4 acceptance radius and the rounding of the subdivision
+        sl.ylo -= grow;
+        sl.yhi += grow;
+        sl.r2 = (rmax + grow) * (rmax + grow);
+        sl.pad = 0;
+        bez_slabs.push_back(sl);
+    }
     beziers.push_back(b);
     o.aux = (int)beziers.size() - 1;
     objs.push_back(o);

@@ -55,6 +55,7 @@ struct HostScene {
     std::vector<HostTree> trees;
     std::vector<HostTexture> textures;
     std::vector<BezierRec> beziers;
+    std::vector<BezSlabRec> bez_slabs;  // kBezSlabs per Bezier object (see BezSlabRec)
     std::vector<double> cover;  // (cx, cy, cz, r) spheres that together contain every mesh triangle (classify_kernel)
     std::string error;
 

@@ -288,6 +288,9 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         if ((rc = upload(s, texs, &d.texs))) return rc;
         if ((rc = upload(s, texels, &d.texels))) return rc;
         if ((rc = upload(s, H.beziers, &d.beziers))) return rc;
+        if ((rc = upload(s, H.bez_slabs, &d.bez_slabs))) return rc;
+        // CGRT_NO_BEZIER_CULL=1 (measurement / test aid, read at every commit): run every solve of every ray that enters the box
+        if (const char *e = std::getenv("CGRT_NO_BEZIER_CULL")) if (*e && *e != '0') d.bez_slabs = nullptr;
         if ((rc = upload(s, hfields, &d.hfields))) return rc;
         if ((rc = upload(s, hcells, &d.hcells))) return rc;
         if ((rc = upload(s, otris, &d.otris))) return rc;

@@ -220,7 +220,9 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             double len = 0;
             V3 nrm = best.n;  // the reference passes its running `temp` normal (main.cpp:53,56)
             uint32_t n0 = rk.explicit_key ? rk.n0 : 0u;
-            const bool bh = bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, n0, len, nrm, aux.bl);
+            const int bi = __builtin_amdgcn_readfirstlane(ob.aux);
+            const bool bh = bezier_wave(bz, ld3(ob.a), ob.b[0], on, o, d, key, n0, len, nrm, aux.bl,
+                                        (rk.explicit_key || !sc.bez_slabs) ? nullptr : sc.bez_slabs + (size_t)bi * kBezSlabs);
             if (rk.explicit_key) rk.n0 = n0;
             if (bh) {
                 if (len < best.t) {

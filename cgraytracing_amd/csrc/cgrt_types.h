@@ -134,6 +134,15 @@ struct BezierRec {
     double box[6];  // xmin,xmax,ymin,ymax,zmin,zmax (bezier.h:64-69)
 };
 
+// A Bezier surface of revolution in kBezSlabs pieces of its parameter range: the piece u in [k, k+1] / kBezSlabs lies between
+// the heights ylo..yhi (relative to the object's position) and within radius sqrt(r2) of the axis -- hull of the piece's own
+// control points, grown by 1e-3.  A ray that stays outside every piece's cylinder within that piece's heights cannot come
+// within 1e-4 of the surface, so none of Bezier::intersect's solves could be accepted (bezier.h:257).
+struct BezSlabRec {
+    double ylo, yhi, r2, pad;
+};
+static constexpr int kBezSlabs = 32;
+
 // Kernel argument block.
 struct DeviceScene {
     const ObjRec *objs;
@@ -148,6 +157,7 @@ struct DeviceScene {
     const OTriRec *otris;
     const NodeRec *tboxes;
     const WideNodeRec *wnodes;
+    const BezSlabRec *bez_slabs;  // n_beziers x kBezSlabs
     const double *cover;  // n_cover x (cx, cy, cz, r): spheres that together contain every mesh triangle
     int32_t n_objs, n_trees, n_texs, n_beziers;
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)

@@ -688,3 +688,27 @@ def test_wide_walk_with_a_deep_stack(gpu_ready, orc, refl, lens):
     assert np.array_equal(got["rgb"], nat["rgb"]) and np.array_equal(got["nhit"], nat["nhit"]) and got["nrays"] == nat["nrays"]
     assert got["nrays"] == want["nrays"] and np.array_equal(got["nhit"], want["nhit"])
     assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
+
+
+def test_bezier_shell_cull_changes_nothing(gpu_ready, monkeypatch):
+    """Rays that enter a Bezier object's box but cannot come within the acceptance radius of its surface (piecewise cylinder
+    bounds, cgrt_bezier.hpp bez_shell_maybe) skip the ten Newton solves.  No such solve could have been accepted, so the frame
+    must be the one rendered with every solve run (CGRT_NO_BEZIER_CULL=1 at commit): identical bits, hit counts and ray count --
+    on the C5-shaped scene (vase beside a bump floor, thin lens, reflections off the vase and onto it) and on a squat Bezier
+    object near the camera seen through a pinhole."""
+    import cgraytracing_amd as cg
+    cases = [(scenes.scene_c5(scenes.stone_small_texture(True)), scenes.cam_dof(), 640, 480, 4),
+             (scenes.planes() + [scenes.Sphere((-6.0, -14.0, 22.0), 4.0, (0.9, 0.9, 0.9), 0.8, 0.0),
+                                 scenes.Bezier([(0, -3, 1.2), (0, 0.5, 3.2), (0, -0.5, 0.2), (0, 3, 2.6)], (3.0, -12.0, 18.0), (1.0, 1.0, 1.0), 0.5, 0.0)],
+              scenes.cam_pinhole(), 512, 384, 4)]
+    for objs, cam, W, H, spp in cases:
+        with cg.Scene(objs) as sc:
+            fast = sc.trace_grid_host(W, H, spp, cam, 5, 11)
+        monkeypatch.setenv("CGRT_NO_BEZIER_CULL", "1")
+        with cg.Scene(objs) as sc:
+            full = sc.trace_grid_host(W, H, spp, cam, 5, 11)
+        monkeypatch.delenv("CGRT_NO_BEZIER_CULL")
+        assert fast["nrays"] == full["nrays"] and np.array_equal(fast["nhit"], full["nhit"])
+        assert np.array_equal(fast["rgb"], full["rgb"])
+        assert fast["nrays"] > W * H * spp * 1.01  # the object is seen and reflects
+
