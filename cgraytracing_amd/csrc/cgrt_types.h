@@ -141,7 +141,7 @@ struct BezierRec {
 struct BezSlabRec {
     double ylo, yhi, r2, pad;
 };
-static constexpr int kBezSlabs = 32;
+static constexpr int kBezSlabs = 64;
 
 // Kernel argument block.
 struct DeviceScene {
