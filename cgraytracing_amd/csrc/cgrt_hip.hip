@@ -330,13 +330,15 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     }
     // light tiles (classify_kernel): possible when planes are plain diffuse surfaces and something else is not
     {
-        bool planes_plain = true, special = false;
+        bool planes_plain = true, special = false, plane_trees = false;
         for (auto &o : H.objs) {
             const bool diffuse = o.refl < kEps && o.transp < kEps;
-            if (o.kind == KIND_PLANE && (!diffuse || o.tree >= 0)) planes_plain = false;
+            if (o.kind == KIND_PLANE && !diffuse) planes_plain = false;  // a bump map is fine: a diffuse bumped floor still ends the path
+            if (o.kind == KIND_PLANE && o.tree >= 0) plane_trees = true;
             if (o.kind == KIND_MESH || o.kind == KIND_BEZIER || (o.kind == KIND_SPHERE && !diffuse)) special = true;
         }
         d.light_ok = (planes_plain && special && !d.all_spheres) ? 1 : 0;
+        d.light_trees = plane_trees ? 1 : 0;  // the light variant then needs the tree / height-field code (not Bezier, not glass)
         if (d.light_ok && !s->aux_stream) {
             // the light launch yields to the scheduled one: lowest stream priority
             int prio_least = 0, prio_greatest = 0;
@@ -710,15 +712,17 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
             gl.timeline = nullptr;
             HIP_TRY(hipEventRecord(s->ev_fork, st));
             HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
-            const size_t lds_light = (size_t)s->dev.n_objs * sizeof(ObjRec);
+            size_t lds_light = (size_t)s->dev.n_objs * sizeof(ObjRec);
+            const bool ltrees = s->dev.light_trees != 0;  // bump-mapped planes: the tree-capable variant (same LDS carve-up as the main launch's)
+            if (ltrees && s->dev.cached_tree >= 0) lds_light += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
+            if (ltrees && s->dev.has_wide) lds_light += (size_t)kThreads * kWideLdsDepth * sizeof(uint2);
             const dim3 gd_light((unsigned)tile_grid_blocks(g.W, g.rows, false));
             gl.xcd_tiles = 0;
-            if (dof)
-                hipLaunchKernelGGL((trace_grid_kernel<false, false, true, false, false, false>), gd_light, dim3(kThreads), lds_light,
-                                   s->aux_stream, s->dev, gl, rgb, nhit, cnt);
-            else
-                hipLaunchKernelGGL((trace_grid_kernel<false, false, false, false, false, false>), gd_light, dim3(kThreads), lds_light,
-                                   s->aux_stream, s->dev, gl, rgb, nhit, cnt);
+#define LIGHT(T, D) hipLaunchKernelGGL((trace_grid_kernel<T, false, D, false, false, false>), gd_light, dim3(kThreads), lds_light, \
+                                       s->aux_stream, s->dev, gl, rgb, nhit, cnt)
+            if (ltrees) { if (dof) LIGHT(true, true); else LIGHT(true, false); }
+            else        { if (dof) LIGHT(false, true); else LIGHT(false, false); }
+#undef LIGHT
             HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
         }
         // heavy: cost x spp > (total cost x spp / wave slots) / heavy_div

@@ -167,7 +167,8 @@ struct DeviceScene {
     int32_t cached_tree; // tree whose nodes every workgroup stages in LDS (-1: none)
     int32_t cached_nodes;
     int32_t has_wide;    // some tree is walked in its 4-wide form (the eye kernels' LDS stack)
-    int32_t light_ok;    // every plane is diffuse and un-bumped and some object is "special" (mesh, Bezier, mirror or glass
+    int32_t light_trees; // light_ok and some plane is bump-mapped: the light variant is the tree-capable one
+    int32_t light_ok;    // every plane is diffuse (bump-mapped or not) and some object is "special" (mesh, Bezier, mirror or glass
                          // sphere): tiles whose primary rays provably stay clear of the special objects' bounding spheres see
                          // diffuse spheres and planes only and may be rendered by the light kernel variant (cgrt_hip.hip)
     int32_t n_cover;
