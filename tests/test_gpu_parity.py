@@ -583,7 +583,7 @@ def test_cost_ordered_schedule_changes_nothing(gpu_ready, name, mk, cam, W, H, s
             assert np.array_equal(e["rgb"], f["rgb"]) and np.array_equal(e["counters"][:2], f["counters"][:2])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CGRT_FUZZ_SEEDS_LIGHT", "6"))))
 def test_light_tile_classification_is_conservative(gpu_ready, orc, seed):
     """The light-tile split: frames with plain diffuse planes and small "special" objects -- a mesh, a
     mirror and a glass sphere, a Bezier vase -- placed near the frame's edge, near the camera, behind other objects and at
@@ -711,4 +711,33 @@ def test_bezier_shell_cull_changes_nothing(gpu_ready, monkeypatch):
         assert fast["nrays"] == full["nrays"] and np.array_equal(fast["nhit"], full["nhit"])
         assert np.array_equal(fast["rgb"], full["rgb"])
         assert fast["nrays"] > W * H * spp * 1.01  # the object is seen and reflects
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CGRT_FUZZ_SEEDS_BIG", "3"))))
+def test_random_large_meshes_match_oracle_exactly(gpu_ready, orc, seed):
+    """Fuzz with trees of real depth: triangle soups of 3 000 to 30 000 triangles of mixed sizes (shared vertices, duplicates,
+    degenerate triangles: _random_mesh) as an opaque, a mirror or a glass object -- the 4-wide walk with its stack for the opaque
+    ones, the leaf-level hierarchy with the per-triangle boxes for the glass ones -- beside a second, small mesh of the other
+    kind, thin lens or pinhole, scheduled launch and image order.  Accumulator, hit counts and ray count equal the oracle's."""
+    import cgraytracing_amd as cg
+    rng = np.random.default_rng(9000 + seed)
+    ntri = int([3000, 12000, 30000][seed % 3])
+    refl, transp = [(0.0, 0.0), (0.8, 0.0), (0.8, 0.5)][(seed // 3 + seed) % 3]
+    big = _random_mesh(rng, ntri, rng.uniform((-6, -12, 24), (6, -2, 32)), float(rng.uniform(6.0, 12.0)), 0.05)
+    # mixed sizes: shrink most triangles towards their first vertex so that boxes nest and overlap at every scale
+    t = big.reshape(-1, 3, 3)
+    shrink = rng.choice([1.0, 0.3, 0.05], size=len(t), p=[0.1, 0.4, 0.5])[:, None, None]
+    big = (t[:, :1, :] + (t - t[:, :1, :]) * shrink).reshape(-1, 9)
+    small = _random_mesh(rng, 60, rng.uniform((-10, -16, 22), (10, 0, 34)), 4.0, 0.1)
+    objs = scenes.planes() + [scenes.TriangleMesh.from_triangles(big, tuple(rng.uniform(0.2, 1.0, 3)), refl, transp),
+                              scenes.TriangleMesh.from_triangles(small, (0.6, 0.7, 0.9), 0.8, 0.5 if transp == 0.0 else 0.0)]
+    cam = scenes.cam_dof() if seed % 2 else scenes.cam_pinhole()
+    W, H, spp = 160, 120, 4
+    want = BackendScene(orc, objs).trace_grid(cam, W, H, spp, 5, seed=40 + seed)
+    with cg.Scene(objs) as sc:
+        got = sc.trace_grid_host(W, H, spp, cam, 5, 40 + seed)
+        nat = sc.trace_grid_host(W, H, spp, cam, 5, 40 + seed, reorder=False)
+    assert np.array_equal(got["rgb"], nat["rgb"]) and np.array_equal(got["nhit"], nat["nhit"]) and got["nrays"] == nat["nrays"]
+    assert got["nrays"] == want["nrays"] and np.array_equal(got["nhit"], want["nhit"])
+    assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
 
