@@ -551,17 +551,20 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     ON_DEVICE(s->device);
     const GridVariant gv = grid_variant(s, cam, grid);
     const bool trees = s->dev.has_mesh != 0, dof = gv.dof, bez = gv.bez, glass = gv.glass, stats = gv.stats;
-    // Cost-aware scheduling ("probe -> sort -> plan -> render -> ordered sum").  A frame's cost
+    // Cost-aware scheduling ("classify -> probe -> plan -> render -> ordered sum"; DESIGN.md sections 4.6-4.7).  A frame's cost
     // is concentrated in a few tiles (a glass mesh: one 32x8 tile ran 38 of the frame's 46 ms while four of the eight XCDs
     // were idle after 6 ms), the hardware hands out workgroups in block-index order, and a tile is bound to one wave per
-    // 64 pixels.  So: (1) the same kernel traces ONE sample of every wave tile (16x4 pixels) storing nothing but the
-    // shader-clock ticks it took; (2) the wave tiles are sorted by that cost (hipcub radix sort, 4 bytes per wave tile);
-    // (3) plan_kernel marks as HEAVY the tiles that alone would hold a wave slot for more than 1/kHeavyDiv of the frame's
-    // ideal duration; (4) the render launch serves the heavy tiles first, through a queue of (pixel, sample) units that any
-    // lane of any heavy wave may take (GridParams), and renders the rest in image order; (5) deferred_sum_kernel adds the
-    // heavy tiles' Hitpoint values in the reference's order.  The image does not depend on any of this -- every Hitpoint
-    // value is added to its pixel in sample order, emission order within a sample --: identical bits and counters; the probe
-    // costs 1/spp of the frame and the whole scheme is skipped below 4 samples per pixel or on request (CGRT_GRID_NO_REORDER).
+    // 64 pixels.  So: (0) classify_kernel marks the LIGHT wave tiles (no primary ray can reach a mesh, a Bezier object or a
+    // reflecting / refracting sphere), which a lighter kernel variant renders on a second stream; (1) the full variant traces
+    // ONE sample of every other wave tile (16x4 pixels) storing nothing but the shader-clock ticks it took; (2) plan_kernel
+    // marks as HEAVY the tiles that alone would hold a wave slot for more than 1/heavy_div of the frame's ideal duration,
+    // orders them heaviest first, and lists the remaining tiles with something to render, costliest first; (3) the render
+    // launch serves the heavy tiles through a queue of (pixel, sample) units that any lane of any wave may take, and the
+    // other tiles through a queue of tiles, with persistent workgroups serving both (GridParams); (4) deferred_sum_kernel
+    // adds the heavy tiles' Hitpoint values in the reference's order.  The image does not depend on any of this -- every
+    // Hitpoint value is added to its pixel in sample order, emission order within a sample --: identical bits and counters;
+    // the probe costs 1/spp of the frame and the whole scheme is skipped below 4 samples per pixel or on request
+    // (CGRT_GRID_NO_REORDER).
     const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW, wtiles_y = (g.rows + kWaveTileH - 1) / kWaveTileH;
     const size_t n_wt = (size_t)wtiles_x * wtiles_y;
     static const bool env_force_reorder = [] { const char *e = std::getenv("CGRT_FORCE_REORDER"); return e && *e && *e != '0'; }();
