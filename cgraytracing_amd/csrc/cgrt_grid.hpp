@@ -16,21 +16,24 @@ struct GridParams {
     int32_t chunks, chunk_spp;
     double *partial;
     uint32_t *partial_nhit;
-    // Cost-aware scheduling (cgrt_hip.hip, "probe -> sort -> plan -> render -> ordered sum").  The unit of
+    // Cost-aware scheduling (cgrt_hip.hip, "classify -> probe -> plan -> render -> ordered sum").  The unit of
     // bookkeeping is a WAVE TILE of 16x4 pixels, numbered wy * ceil(W/16) + wx over the local rows.
     //   probe != 0 : trace this launch's first sample only to measure it -- nothing is stored except cost[wave tile] =
     //                shader-clock ticks the wave spent on it.
-    //   render     : order[0..K) = the HEAVY wave tiles (plan_kernel), plan[0] = K, hidx[wave tile] = rank among them or -1.  A first launch (the HEAVY kernel variant, heavy_blocks workgroups that
-    //                loop until the queue is empty) serves the heavy tiles through a queue of ITEMS (plan[2] = next item; item = heavy tile rank * items_per_tile + part): an item is
-    //                units_per_item (pixel, sample) UNITS of one heavy tile, which the lanes of the wave take one after
-    //                another as they become free, so a heavy tile is spread over many waves on many CUs and no lane idles
-    //                while units remain.  Every Hitpoint value of a unit goes to dvals[rank][sample][emission index][pixel]
-    //                (dcnt = how many), and deferred_sum_kernel adds them per pixel in the reference's order -- sample by
-    //                sample, emission order within a sample -- so the fp64 sum is bit for bit the sequential one.  The
-    //                tile launch renders the other tiles in image order (waves whose tile is heavy stand down).
+    //   render     : order[0..K) = the HEAVY wave tiles (plan_kernel), plan[0] = K, hidx[wave tile] = rank among them or -1.
+    //                The first heavy_blocks workgroups of the render launch (the unit-form body; they loop until the queue
+    //                is empty) serve the heavy tiles through a queue of ITEMS (plan[2] = next item; item = heavy tile rank *
+    //                items_per_tile + part): an item is units_per_item (pixel, sample) UNITS of one heavy tile, which the
+    //                lanes of the wave take one after another as they become free, so a heavy tile is spread over many waves
+    //                on many CUs and no lane idles while units remain.  Every Hitpoint value of a unit goes to
+    //                dvals[rank][sample][emission index][pixel] (dcnt = how many), and deferred_sum_kernel adds them per
+    //                pixel in the reference's order -- sample by sample, emission order within a sample -- so the fp64 sum
+    //                is bit for bit the sequential one.  The other tiles are rendered in the tile form (waves whose tile is
+    //                heavy stand down): through the tile queue below, or one workgroup per tile.
     // Light tiles (classify_kernel): light[wave tile] != 0 -- no primary ray of the tile can come near a mesh, a Bezier
     // object or a mirror / glass sphere, so it is rendered by the kernel variant without tree, Bezier and pending-ray code
-    // (fewer registers, more waves per SIMD), launched beside the full variant on a second stream.  light_mode: 0 = this
+    // (fewer registers, more waves per SIMD; with bump-mapped diffuse planes: the tree-capable variant without Bezier and
+    // pending-ray code), launched beside the full variant on a second stream.  light_mode: 0 = this
     // launch leaves the light tiles alone, 1 = this launch renders only them; light == nullptr: no split.
     const unsigned char *light;
     int32_t light_mode, pad_light_;
