@@ -17,7 +17,7 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
 // SPH: every object is a sphere (C1/C2-type scenes): specialised object loop.
 // HPS: additionally append every Hitpoint {f, pos, normal} (hitpoints.h:6-20, main.cpp:87-98) to a global stream.
 #ifndef CGRT_BEZ_WAVES
-#define CGRT_BEZ_WAVES 3
+#define CGRT_BEZ_WAVES 2
 #endif
 static constexpr int kBezWaves = CGRT_BEZ_WAVES;  // waves per SIMD the Bezier variants are compiled for
 
