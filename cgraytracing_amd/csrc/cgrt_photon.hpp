@@ -71,7 +71,8 @@ __global__ void hp_keys_kernel(const double *__restrict__ rec, long long n, Hash
 // sorted order -> structure of arrays + per-bucket start offsets
 __global__ void hp_gather_kernel(const double *__restrict__ rec, const unsigned long long *__restrict__ keys,
                                  const unsigned int *__restrict__ vals, long long n, double r2_init,
-                                 double *__restrict__ hp /* n x 16 */, int *__restrict__ bucket_of) {
+                                 double *__restrict__ hp /* n x 16 */, double *__restrict__ hps /* n x 8 */,
+                                 int *__restrict__ bucket_of) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double *q = rec + 10 * (long long)vals[i];
@@ -83,6 +84,11 @@ __global__ void hp_gather_kernel(const double *__restrict__ rec, const unsigned 
     o[11] = 0; o[12] = 0; o[13] = 0;
     o[14] = r2_init;
     o[15] = 0;
+    // what the pair search reads, in half a cache line: pos, normal, batch-start r2
+    double *c = hps + 8 * i;
+    for (int k = 0; k < 6; k++) c[k] = q[3 + k];
+    c[6] = r2_init;
+    c[7] = 0;
     bucket_of[i] = (int)(keys[i] >> 44);
 }
 __global__ void bucket_start_kernel(const int *__restrict__ bucket_of, long long n, int hashsize, int *__restrict__ bstart) {
@@ -252,7 +258,7 @@ __device__ __forceinline__ void pairs_flush(const unsigned long long *buf, unsig
 __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restrict__ events,
                                                            const unsigned int *__restrict__ order_keys,
                                                            const unsigned int *__restrict__ order, int nslots, HashArgs ha,
-                                                           const double *__restrict__ hp, const int *__restrict__ bstart,
+                                                           const double *__restrict__ hps, const int *__restrict__ bstart,
                                                            unsigned long long *__restrict__ keys,
                                                            unsigned int *__restrict__ vals,
                                                            unsigned long long *__restrict__ npairs /* [0] pairs, [1] events */,
@@ -294,9 +300,9 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
                 }
                 bool hit = false;
                 if (i < i1) {
-                    const double *h = hp + 16 * (size_t)i;
-                    const V3 dd = mk(h[5], h[6], h[7]) - P;
-                    hit = (dot(mk(h[8], h[9], h[10]), n) > kEps) && (dot(dd, dd) <= h[14]);  // main.cpp:116, batch-start r2
+                    const double *h = hps + 8 * (size_t)i;
+                    const V3 dd = mk(h[0], h[1], h[2]) - P;
+                    hit = (dot(mk(h[3], h[4], h[5]), n) > kEps) && (dot(dd, dd) <= h[6]);  // main.cpp:116, batch-start r2
                 }
                 const unsigned long long m = __ballot(hit);
                 if (hit) buf[cnt + (unsigned)__popcll(m & lt)] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
 // 4. ordered replay per hitpoint
 __global__ void photon_apply_kernel(const unsigned long long *__restrict__ keys, const unsigned int *__restrict__ vals,
                                     unsigned int npairs, const double *__restrict__ events, double alpha,
-                                    double *__restrict__ hp, long long nhp) {
+                                    double *__restrict__ hp, double *__restrict__ hps, long long nhp) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nhp) return;
     const unsigned long long klo = (unsigned long long)i << 24;
@@ -354,6 +360,7 @@ __global__ void photon_apply_kernel(const unsigned long long *__restrict__ keys,
     h[11] = flux.x; h[12] = flux.y; h[13] = flux.z;
     h[14] = r2;
     h[15] = (double)n;
+    hps[8 * i + 6] = r2;  // the next batch's search radius
 }
 
 // final gather, main.cpp:252-258: per pixel, in table order
@@ -387,32 +394,105 @@ __global__ void image_keys_kernel(const double *__restrict__ hp, long long nhp, 
     vals[i] = (unsigned int)i;
 }
 
-int sort_pairs(unsigned long long *kin, unsigned long long *kout, unsigned int *vin, unsigned int *vout, size_t n,
-               int end_bit = 64) {
+// Grow-only scratch for the radix sorts: hipMalloc / hipFree per sort would drain the device (hipFree synchronises)
+// twice per photon batch.
+struct SortTemp {
+    DevBuf buf;
+    size_t cap = 0;
+    hipError_t need(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (buf.p) {
+            (void)hipFree(buf.p);
+            buf.p = nullptr;
+            cap = 0;
+        }
+        const hipError_t e = buf.alloc(bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+};
+
+int sort_pairs(SortTemp &tmp, unsigned long long *kin, unsigned long long *kout, unsigned int *vin, unsigned int *vout, size_t n,
+               int end_bit = 64, hipStream_t st = 0) {
     size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, 0));
-    DevBuf tmp;
-    HIP_TRY(tmp.alloc(tmp_bytes));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, 0));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, st));
+    HIP_TRY(tmp.need(tmp_bytes));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, st));
     return CGRT_OK;
 }
 
-void launch_photon_trace(const cgrt_scene *s, const PhotonArgs &pa, double *events, unsigned char *valid) {
+void launch_photon_trace(const cgrt_scene *s, const PhotonArgs &pa, double *events, unsigned char *valid, hipStream_t st = 0) {
     const dim3 grid((pa.count + kThreads - 1) / kThreads), block(kThreads);
     const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
     if (s->dev.has_bezier)
-        hipLaunchKernelGGL(photon_trace_kernel<true>, grid, block, lds + (kThreads / 64) * sizeof(BezLds), 0, s->dev, pa, events,
+        hipLaunchKernelGGL(photon_trace_kernel<true>, grid, block, lds + (kThreads / 64) * sizeof(BezLds), st, s->dev, pa, events,
                            valid);
     else
-        hipLaunchKernelGGL(photon_trace_kernel<false>, grid, block, lds, 0, s->dev, pa, events, valid);
+        hipLaunchKernelGGL(photon_trace_kernel<false>, grid, block, lds, st, s->dev, pa, events, valid);
 }
 
-int sort_pairs32(unsigned int *kin, unsigned int *kout, unsigned int *vin, unsigned int *vout, size_t n) {
+int sort_pairs32(SortTemp &tmp, unsigned int *kin, unsigned int *kout, unsigned int *vin, unsigned int *vout, size_t n,
+                 hipStream_t st = 0) {
     size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, 0));
-    DevBuf tmp;
-    HIP_TRY(tmp.alloc(tmp_bytes));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, 0));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st));
+    HIP_TRY(tmp.need(tmp_bytes));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st));
+    return CGRT_OK;
+}
+
+// The producer side of a photon batch (trace -> event keys -> events in hash-cell order) on its own stream, so that the
+// batch after the one being replayed is traced meanwhile: photon paths do not depend on hitpoints.
+struct PhotonProducer {
+    hipStream_t st = nullptr;
+    hipEvent_t produced[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    DevBuf ev[2], valid[2], ek0[2], ek1[2], eo0[2], eo1[2];
+    SortTemp tmp;
+    ~PhotonProducer() {
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+        for (int k = 0; k < 2; k++) {
+            if (produced[k]) (void)hipEventDestroy(produced[k]);
+            if (consumed[k]) (void)hipEventDestroy(consumed[k]);
+        }
+    }
+    int init(int nbuf, size_t nslots_max, bool own_stream) {
+        if (own_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int k = 0; k < nbuf; k++) {
+            HIP_TRY(hipEventCreateWithFlags(&produced[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&consumed[k], hipEventDisableTiming));
+            HIP_TRY(ev[k].alloc(nslots_max * 9 * sizeof(double)));
+            HIP_TRY(valid[k].alloc(nslots_max));
+            HIP_TRY(ek0[k].alloc(nslots_max * 4)); HIP_TRY(ek1[k].alloc(nslots_max * 4));
+            HIP_TRY(eo0[k].alloc(nslots_max * 4)); HIP_TRY(eo1[k].alloc(nslots_max * 4));
+        }
+        return CGRT_OK;
+    }
+    // enqueue batch `pa` into buffer b (after the replay that last read b has finished)
+    int produce(const cgrt_scene *s, const PhotonArgs &pa, const HashArgs &ha, int b);
+    // null stream: the replay of buffer b is enqueued; b may be overwritten once it has run
+    int release(int b) {
+        HIP_TRY(hipEventRecord(consumed[b], 0));
+        used[b] = true;
+        return CGRT_OK;
+    }
+};
+
+int PhotonProducer::produce(const cgrt_scene *s, const PhotonArgs &pa, const HashArgs &ha, int b) {
+    const int T = 256;
+    const int nslots = pa.count * kSegStride;
+    if (used[b]) HIP_TRY(hipStreamWaitEvent(st, consumed[b], 0));
+    HIP_TRY(hipMemsetAsync(valid[b].p, 0, (size_t)nslots, st));
+    launch_photon_trace(s, pa, ev[b].as<double>(), valid[b].as<unsigned char>(), st);
+    hipLaunchKernelGGL(event_keys_kernel, dim3((nslots + T - 1) / T), dim3(T), 0, st, ev[b].as<double>(), valid[b].as<unsigned char>(),
+                       nslots, ha, ek0[b].as<unsigned int>(), eo0[b].as<unsigned int>());
+    const int rc = sort_pairs32(tmp, ek0[b].as<unsigned int>(), ek1[b].as<unsigned int>(), eo0[b].as<unsigned int>(),
+                                eo1[b].as<unsigned int>(), (size_t)nslots, st);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(produced[b], st));
     return CGRT_OK;
 }
 
@@ -506,7 +586,8 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     const long long npix = (long long)grid->rows * grid->width;
     const size_t n = (size_t)nhp;
     if (n >= (1ull << 31)) return fail(CGRT_ERR_LIMIT, "photon pass: more than 2^31 hitpoints");
-    DevBuf rec, hp, bucket_of, bstart, k0, k1, v0, v1, img;
+    DevBuf rec, hp, hps, bucket_of, bstart, k0, k1, v0, v1, img;
+    SortTemp main_tmp;
     if (n) {
         double *d_rec = nullptr;
         rc = hitpoints_device(s, cam, grid, nhp, &d_rec, &nhp);
@@ -517,6 +598,7 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     // ---- the reference's table order: (bucket, insertion order) ----
     tm.start();
     HIP_TRY(hp.alloc(n * 16 * sizeof(double)));
+    HIP_TRY(hps.alloc(n * 8 * sizeof(double)));
     HIP_TRY(bucket_of.alloc(n * sizeof(int)));
     HIP_TRY(bstart.alloc(((size_t)ph->hashsize + 2) * sizeof(int)));
     HIP_TRY(k0.alloc(n * 8)); HIP_TRY(k1.alloc(n * 8)); HIP_TRY(v0.alloc(n * 4)); HIP_TRY(v1.alloc(n * 4));
@@ -531,10 +613,10 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     if (n) {
         hipLaunchKernelGGL(hp_keys_kernel, dim3(nb), dim3(T), 0, 0, rec.as<double>(), (long long)n, ha, (int)npix, grid->spp,
                            k0.as<unsigned long long>(), v0.as<unsigned int>());
-        rc = sort_pairs(k0.as<unsigned long long>(), k1.as<unsigned long long>(), v0.as<unsigned int>(), v1.as<unsigned int>(), n);
+        rc = sort_pairs(main_tmp, k0.as<unsigned long long>(), k1.as<unsigned long long>(), v0.as<unsigned int>(), v1.as<unsigned int>(), n);
         if (rc) return rc;
         hipLaunchKernelGGL(hp_gather_kernel, dim3(nb), dim3(T), 0, 0, rec.as<double>(), k1.as<unsigned long long>(),
-                           v1.as<unsigned int>(), (long long)n, r0 * r0, hp.as<double>(), bucket_of.as<int>());
+                           v1.as<unsigned int>(), (long long)n, r0 * r0, hp.as<double>(), hps.as<double>(), bucket_of.as<int>());
     }
     hipLaunchKernelGGL(bucket_start_kernel, dim3((ph->hashsize + 1 + T - 1) / T), dim3(T), 0, 0, bucket_of.as<int>(),
                        (long long)n, ph->hashsize, bstart.as<int>());
@@ -545,41 +627,63 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     int batch = ph->batch > 0 ? (ph->batch < (1 << 20) ? ph->batch : (1 << 20)) : (1 << 20);
     const int batch_max = batch;
     const int nslots_max = batch * kSegStride;
-    DevBuf ev, valid, pk0, pk1, pv0, pv1, npairs, ek0, ek1, eo0, eo1;
+    DevBuf pk0, pk1, pv0, pv1, npairs;
     // pairs per batch: room for 128 per hitpoint, between 4 M and 128 M (3 GiB of keys and values); a batch that overflows is halved
     const unsigned long long want_cap = (unsigned long long)n * 128ull;
     unsigned long long pair_cap = want_cap < (1ull << 22) ? (1ull << 22) : (want_cap > (1ull << 27) ? (1ull << 27) : want_cap);
     if (ph->pair_cap > 0) pair_cap = (unsigned long long)ph->pair_cap < (1ull << 27) ? (unsigned long long)ph->pair_cap : (1ull << 27);
-    HIP_TRY(ev.alloc((size_t)nslots_max * 9 * sizeof(double)));
-    HIP_TRY(valid.alloc((size_t)nslots_max));
+    // Two event buffers: while batch k's pairs are sorted and replayed (null stream), batch k+1 is traced and its events are
+    // put in hash-cell order on the producer's stream.  CGRT_PHOTON_OVERLAP=0: one buffer, everything on the null stream.
+    const char *ov = std::getenv("CGRT_PHOTON_OVERLAP");
+    const bool overlap = !(ov && ov[0] == '0') && ph->nphotons > batch;
+    PhotonProducer pp;
+    if (n > 0 && ph->nphotons > 0) {
+        rc = pp.init(overlap ? 2 : 1, (size_t)nslots_max, overlap);
+        if (rc) return rc;
+    }
     HIP_TRY(pk0.alloc((size_t)pair_cap * 8)); HIP_TRY(pk1.alloc((size_t)pair_cap * 8));
     HIP_TRY(pv0.alloc((size_t)pair_cap * 4)); HIP_TRY(pv1.alloc((size_t)pair_cap * 4));
-    HIP_TRY(ek0.alloc((size_t)nslots_max * 4)); HIP_TRY(ek1.alloc((size_t)nslots_max * 4));
-    HIP_TRY(eo0.alloc((size_t)nslots_max * 4)); HIP_TRY(eo1.alloc((size_t)nslots_max * 4));
     HIP_TRY(npairs.alloc(16));
     out->n_events = 0;
     out->n_pairs = 0;
     out->n_batch_halvings = 0;
     int pair_key_bits = 25;  // key = hitpoint << 24 | slot
     while (pair_key_bits < 64 && (n >> (pair_key_bits - 24)) != 0) pair_key_bits++;
-    for (long long first = 0; first < ph->nphotons && n > 0;) {
+    auto batch_args = [&](long long first, int batch_now) {
         PhotonArgs pa;
         for (int k = 0; k < 3; k++) pa.light[k] = ph->light[k];
         pa.jitter = ph->jitter; pa.power = ph->power; pa.alpha = ph->alpha;
         pa.first = first;
-        pa.count = (int)((ph->nphotons - first < batch) ? (ph->nphotons - first) : batch);
+        pa.count = (int)((ph->nphotons - first < batch_now) ? (ph->nphotons - first) : batch_now);
         pa.max_depth = grid->max_depth;
         pa.seed = ph->seed;
+        return pa;
+    };
+    long long ahead_first = -1;  // the batch already enqueued on the producer: its range and buffer
+    int ahead_count = 0, ahead_buf = 0, cur = 0;
+    for (long long first = 0; first < ph->nphotons && n > 0;) {
+        const PhotonArgs pa = batch_args(first, batch);
         const int nslots = pa.count * kSegStride;
-        HIP_TRY(hipMemsetAsync(valid.p, 0, (size_t)nslots, 0));
+        if (ahead_first == pa.first && ahead_count == pa.count) {
+            cur = ahead_buf;
+        } else {  // first batch, or the plan changed (a halving): produce it now
+            rc = pp.produce(s, pa, ha, cur);
+            if (rc) return rc;
+        }
+        ahead_first = -1;
+        if (overlap && first + pa.count < ph->nphotons) {
+            // Enqueue the NEXT batch now, so that it is traced under this batch's search, sort and replay.  Its range assumes
+            // this batch neither overflows the pair buffer nor changes the batch size; if it does, the range will not match
+            // at the top of the loop and the batch is produced again (results do not depend on the batching).
+            const PhotonArgs nx = batch_args(first + pa.count, batch);
+            rc = pp.produce(s, nx, ha, 1 - cur);
+            if (rc) return rc;
+            ahead_first = nx.first; ahead_count = nx.count; ahead_buf = 1 - cur;
+        }
+        if (pp.st) HIP_TRY(hipStreamWaitEvent(0, pp.produced[cur], 0));
         HIP_TRY(hipMemsetAsync(npairs.p, 0, 16, 0));
-        launch_photon_trace(s, pa, ev.as<double>(), valid.as<unsigned char>());
-        hipLaunchKernelGGL(event_keys_kernel, dim3((nslots + T - 1) / T), dim3(T), 0, 0, ev.as<double>(), valid.as<unsigned char>(),
-                           nslots, ha, ek0.as<unsigned int>(), eo0.as<unsigned int>());
-        rc = sort_pairs32(ek0.as<unsigned int>(), ek1.as<unsigned int>(), eo0.as<unsigned int>(), eo1.as<unsigned int>(), (size_t)nslots);
-        if (rc) return rc;
-        hipLaunchKernelGGL(photon_pairs_kernel, dim3((nslots + T - 1) / T), dim3(T), 0, 0, ev.as<double>(),
-                           ek1.as<unsigned int>(), eo1.as<unsigned int>(), nslots, ha, hp.as<double>(), bstart.as<int>(),
+        hipLaunchKernelGGL(photon_pairs_kernel, dim3((nslots + T - 1) / T), dim3(T), 0, 0, pp.ev[cur].as<double>(),
+                           pp.ek1[cur].as<unsigned int>(), pp.eo1[cur].as<unsigned int>(), nslots, ha, hps.as<double>(), bstart.as<int>(),
                            pk0.as<unsigned long long>(), pv0.as<unsigned int>(), npairs.as<unsigned long long>(), pair_cap);
         HIP_TRY(hipGetLastError());
         unsigned long long np2[2] = {0, 0};  // pairs (the full 64-bit count, stored or not), events
@@ -588,21 +692,27 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
             if (pa.count <= 1) return fail(CGRT_ERR_LIMIT, "photon pass: one photon's pairs exceed the pair buffer");
             batch = (pa.count < batch ? pa.count : batch) / 2;
             out->n_batch_halvings++;
+            rc = pp.release(cur);
+            if (rc) return rc;
             continue;
         }
         const unsigned int np = (unsigned int)np2[0];  // <= pair_cap <= 2^27
         first += pa.count;
         out->n_events += np2[1];
         if (batch < batch_max && np < pair_cap / 4) batch *= 2;  // radii shrink as photons arrive: later batches hold fewer pairs
-        if (np == 0) continue;
-        out->n_pairs += np;
-        rc = sort_pairs(pk0.as<unsigned long long>(), pk1.as<unsigned long long>(), pv0.as<unsigned int>(), pv1.as<unsigned int>(), np,
-                        pair_key_bits);
+        if (np != 0) {
+            out->n_pairs += np;
+            rc = sort_pairs(main_tmp, pk0.as<unsigned long long>(), pk1.as<unsigned long long>(), pv0.as<unsigned int>(),
+                            pv1.as<unsigned int>(), np, pair_key_bits);
+            if (rc) return rc;
+            hipLaunchKernelGGL(photon_apply_kernel, dim3(nb), dim3(T), 0, 0, pk1.as<unsigned long long>(), pv1.as<unsigned int>(), np,
+                               pp.ev[cur].as<double>(), ph->alpha, hp.as<double>(), hps.as<double>(), (long long)n);
+            HIP_TRY(hipGetLastError());
+        }
+        rc = pp.release(cur);
         if (rc) return rc;
-        hipLaunchKernelGGL(photon_apply_kernel, dim3(nb), dim3(T), 0, 0, pk1.as<unsigned long long>(), pv1.as<unsigned int>(), np,
-                           ev.as<double>(), ph->alpha, hp.as<double>(), (long long)n);
-        HIP_TRY(hipGetLastError());
     }
+    if (pp.st) HIP_TRY(hipStreamSynchronize(pp.st));
     out->ms_photons = tm.stop();
     // ---- final gather + tone map ----
     tm.start();
@@ -611,7 +721,7 @@ extern "C" int cgrt_ppm_render(const cgrt_scene *s, const cgrt_camera *cam, cons
     if (n) {
         hipLaunchKernelGGL(image_keys_kernel, dim3(nb), dim3(T), 0, 0, hp.as<double>(), (long long)n, grid->spp,
                            k0.as<unsigned long long>(), v0.as<unsigned int>());
-        rc = sort_pairs(k0.as<unsigned long long>(), k1.as<unsigned long long>(), v0.as<unsigned int>(), v1.as<unsigned int>(), n);
+        rc = sort_pairs(main_tmp, k0.as<unsigned long long>(), k1.as<unsigned long long>(), v0.as<unsigned int>(), v1.as<unsigned int>(), n);
         if (rc) return rc;
         hipLaunchKernelGGL(photon_image_kernel, dim3((unsigned)((npix + T - 1) / T)), dim3(T), 0, 0, k1.as<unsigned long long>(),
                            v1.as<unsigned int>(), (long long)n, hp.as<double>(), (double)ph->nphotons * grid->spp, npix,

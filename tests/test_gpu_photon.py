@@ -61,6 +61,28 @@ def test_pair_buffer_overflow_path_matches_reference_golden(gpu_ready, case):
     assert np.array_equal(r["image"], g["image"]) and np.array_equal(base["image"], g["image"])
 
 
+def test_producer_stream_overlap_is_invisible(gpu_ready, monkeypatch):
+    """With more photons than one batch the next batch is traced on a second stream while the current one is searched and
+    replayed (cgrt_photon.hpp PhotonProducer), enqueued BEFORE the current batch's pair count is known.  Checked here: the
+    overlapped run equals the single-stream run (CGRT_PHOTON_OVERLAP=0) and the reference golden bit for bit, also when
+    the pair buffer overflows so that batches enqueued ahead no longer match the plan and are produced again."""
+    import cgraytracing_amd as cg
+    name, mk, cam, W, H, spp, nph = make_golden.photon_cases()[0]
+    g = np.load(os.path.join(GOLD, "ppm_%s.npz" % name))
+    with cg.Scene(mk()) as sc:
+        base = sc.ppm_render(W, H, spp, cam(), 5, 12345, nphotons=nph)
+        cap = max(128, base["n_pairs"] // 12)
+        on = sc.ppm_render(W, H, spp, cam(), 5, 12345, nphotons=nph, batch=nph // 7 + 1, want_hitpoints=True)
+        on_ovf = sc.ppm_render(W, H, spp, cam(), 5, 12345, nphotons=nph, batch=nph // 3 + 1, pair_cap=cap, want_hitpoints=True)
+        monkeypatch.setenv("CGRT_PHOTON_OVERLAP", "0")
+        off = sc.ppm_render(W, H, spp, cam(), 5, 12345, nphotons=nph, batch=nph // 7 + 1, want_hitpoints=True)
+    assert on_ovf["n_batch_halvings"] >= 1, on_ovf["n_batch_halvings"]
+    for r in (on, on_ovf, off):
+        assert np.array_equal(r["image"], g["image"])
+        assert np.array_equal(r["hp"], on["hp"])
+    assert on["n_events"] == off["n_events"] == base["n_events"] and on["n_pairs"] == off["n_pairs"]
+
+
 def test_initial_radius_field(gpu_ready, orc):
     """cgrt_photons.initial_radius: 0 is the reference's committed 200/768 (main.cpp:84,183); the same value passed
     explicitly gives the identical image; a host mirroring a reference compiled for another `height` gets another radius,
