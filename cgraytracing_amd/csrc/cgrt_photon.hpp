@@ -283,31 +283,51 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     if (__ballot(on) != 0ull) {
+        int i = 0, i1 = 0, ni = 0, ni1 = 0;
+        if (on) {
+            const unsigned b = ref_hash(ix, iy, iz, ha.hashsize);
+            ni = bstart[b];
+            ni1 = bstart[b + 1];
+        }
         for (int c = 0; c < 27; c++) {
-            int i = 0, i1 = 0;
-            if (on) {
-                const unsigned b = ref_hash(ix + c / 9, iy + (c / 3) % 3, iz + c % 3, ha.hashsize);
-                i = bstart[b];
-                i1 = bstart[b + 1];
+            i = ni; i1 = ni1;
+            ni = ni1 = 0;
+            if (on && c + 1 < 27) {  // the next cell's bucket bounds are fetched under this cell's walk
+                const int c1 = c + 1;
+                const unsigned b = ref_hash(ix + c1 / 9, iy + (c1 / 3) % 3, iz + c1 % 3, ha.hashsize);
+                ni = bstart[b];
+                ni1 = bstart[b + 1];
             }
             while (__ballot(i < i1) != 0ull) {  // all lanes step through their buckets together
-                if (cnt > (unsigned)(kPairBuf - 64)) {  // the next step could overflow: this wave reserves for itself
+                if (cnt > (unsigned)(kPairBuf - 128)) {  // the next step could overflow: this wave reserves for itself
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(npairs, (unsigned long long)cnt);
                     base = __shfl(base, 0);
                     pairs_flush(buf, cnt, base, keys, vals, cap);
                     cnt = 0;
                 }
-                bool hit = false;
+                // two bucket entries per step (their loads in flight together); pair order in the buffer is free, the
+                // pairs are sorted by (hitpoint, slot) afterwards
+                bool hit0 = false, hit1 = false;
                 if (i < i1) {
                     const double *h = hps + 8 * (size_t)i;
-                    const V3 dd = mk(h[0], h[1], h[2]) - P;
-                    hit = (dot(mk(h[3], h[4], h[5]), n) > kEps) && (dot(dd, dd) <= h[6]);  // main.cpp:116, batch-start r2
+                    const bool two = i + 1 < i1;
+                    const double *g = two ? h + 8 : h;
+                    const V3 p0 = mk(h[0], h[1], h[2]), n0 = mk(h[3], h[4], h[5]);
+                    const double r0 = h[6];
+                    const V3 p1 = mk(g[0], g[1], g[2]), n1 = mk(g[3], g[4], g[5]);
+                    const double r1 = g[6];
+                    const V3 d0 = p0 - P, d1 = p1 - P;
+                    hit0 = (dot(n0, n) > kEps) && (dot(d0, d0) <= r0);  // main.cpp:116, batch-start r2
+                    hit1 = two && (dot(n1, n) > kEps) && (dot(d1, d1) <= r1);
                 }
-                const unsigned long long m = __ballot(hit);
-                if (hit) buf[cnt + (unsigned)__popcll(m & lt)] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
-                cnt += (unsigned)__popcll(m);
-                i++;
+                const unsigned long long m0 = __ballot(hit0);
+                if (hit0) buf[cnt + (unsigned)__popcll(m0 & lt)] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
+                cnt += (unsigned)__popcll(m0);
+                const unsigned long long m1 = __ballot(hit1);
+                if (hit1) buf[cnt + (unsigned)__popcll(m1 & lt)] = ((unsigned long long)(i + 1) << 24) | (unsigned long long)s;
+                cnt += (unsigned)__popcll(m1);
+                i += 2;
             }
         }
     }
@@ -347,15 +367,41 @@ __global__ void photon_apply_kernel(const unsigned long long *__restrict__ keys,
     V3 flux = mk(h[11], h[12], h[13]);
     double r2 = h[14];
     int n = (int)h[15];
-    for (unsigned int k = lo; k < npairs && (keys[k] >> 24) == (unsigned long long)i; k++) {
-        const double *e = events + 9 * (size_t)vals[k];
-        const V3 dd = pos - mk(e[0], e[1], e[2]);
-        if (dot(dd, dd) <= r2) {  // main.cpp:116 against the CURRENT radius (the normal test was static)
-            const double g = (n * alpha + alpha) / (n * alpha + 1.0);  // main.cpp:119
-            r2 *= g;
-            n++;
-            flux = (flux + mulv(f, mk(e[6], e[7], e[8])) * (1.0 / kPiRef)) * g;  // main.cpp:122
+    // The replay is a serial chain per hitpoint and the kernel ends with its longest chains, so the loads of kChunk pairs
+    // (key, slot, event: three dependent levels) are issued together and only the update itself runs in sequence.
+    constexpr int kChunk = 4;
+    for (unsigned int k = lo; k < npairs;) {
+        bool mine[kChunk];
+        unsigned int slot[kChunk];
+#pragma unroll
+        for (int c = 0; c < kChunk; c++) {
+            const unsigned int kc = k + (unsigned)c < npairs ? k + (unsigned)c : npairs - 1u;
+            mine[c] = k + (unsigned)c < npairs && (keys[kc] >> 24) == (unsigned long long)i;
+            slot[c] = vals[kc];
         }
+        double e[kChunk][6];
+#pragma unroll
+        for (int c = 0; c < kChunk; c++) {
+            const double *q = events + 9 * (size_t)slot[c];
+            e[c][0] = q[0]; e[c][1] = q[1]; e[c][2] = q[2];
+            e[c][3] = q[6]; e[c][4] = q[7]; e[c][5] = q[8];
+        }
+        bool more = true;
+#pragma unroll
+        for (int c = 0; c < kChunk; c++) {
+            more = more && mine[c];  // the hitpoint's pairs are contiguous: the first foreign key ends the replay
+            if (more) {
+                const V3 dd = pos - mk(e[c][0], e[c][1], e[c][2]);
+                if (dot(dd, dd) <= r2) {  // main.cpp:116 against the CURRENT radius (the normal test was static)
+                    const double g = (n * alpha + alpha) / (n * alpha + 1.0);  // main.cpp:119
+                    r2 *= g;
+                    n++;
+                    flux = (flux + mulv(f, mk(e[c][3], e[c][4], e[c][5])) * (1.0 / kPiRef)) * g;  // main.cpp:122
+                }
+            }
+        }
+        if (!more) break;
+        k += kChunk;
     }
     h[11] = flux.x; h[12] = flux.y; h[13] = flux.z;
     h[14] = r2;
