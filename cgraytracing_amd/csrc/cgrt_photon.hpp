@@ -313,13 +313,20 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
                     const double *h = hps + 8 * (size_t)i;
                     const bool two = i + 1 < i1;
                     const double *g = two ? h + 8 : h;
-                    const V3 p0 = mk(h[0], h[1], h[2]), n0 = mk(h[3], h[4], h[5]);
-                    const double r0 = h[6];
-                    const V3 p1 = mk(g[0], g[1], g[2]), n1 = mk(g[3], g[4], g[5]);
-                    const double r1 = g[6];
-                    const V3 d0 = p0 - P, d1 = p1 - P;
-                    hit0 = (dot(n0, n) > kEps) && (dot(d0, d0) <= r0);  // main.cpp:116, batch-start r2
-                    hit1 = two && (dot(n1, n) > kEps) && (dot(d1, d1) <= r1);
+                    const V3 d0 = mk(h[0], h[1], h[2]) - P, d1 = mk(g[0], g[1], g[2]) - P;  // the reference's differences
+                    // Single-precision screen of the radius test (fewer than 1 in 300 candidates pass it): the fp64
+                    // differences rounded to fp32, their squares summed in fp32 -- all terms >= 0, so the result is within
+                    // 2^-21 relative of the fp64 sum (plus at most 3 * 2^-150 where a square is subnormal); an overflow means
+                    // a distance no radius reaches, a NaN passes the screen.  The bound is r2 * (1 + 2^-18) converted to
+                    // nearest (>= r2 * (1 + 2^-19)) plus 1e-37, so nothing the exact test accepts is screened out; survivors
+                    // take the exact test.
+                    const float ax = (float)d0.x, ay = (float)d0.y, az = (float)d0.z;
+                    const float bx = (float)d1.x, by = (float)d1.y, bz = (float)d1.z;
+                    const float s0 = ax * ax + ay * ay + az * az, s1 = bx * bx + by * by + bz * bz;
+                    const float lim0 = (float)(h[6] * (1.0 + 0x1p-18)) + 1e-37f, lim1 = (float)(g[6] * (1.0 + 0x1p-18)) + 1e-37f;
+                    const bool c0 = !(s0 > lim0), c1 = two && !(s1 > lim1);
+                    if (c0) hit0 = (dot(mk(h[3], h[4], h[5]), n) > kEps) && (dot(d0, d0) <= h[6]);  // main.cpp:116, batch-start r2
+                    if (c1) hit1 = (dot(mk(g[3], g[4], g[5]), n) > kEps) && (dot(d1, d1) <= g[6]);
                 }
                 const unsigned long long m0 = __ballot(hit0);
                 if (hit0) buf[cnt + (unsigned)__popcll(m0 & lt)] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
