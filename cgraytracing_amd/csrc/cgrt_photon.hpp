@@ -84,10 +84,12 @@ __global__ void hp_gather_kernel(const double *__restrict__ rec, const unsigned 
     o[11] = 0; o[12] = 0; o[13] = 0;
     o[14] = r2_init;
     o[15] = 0;
-    // what the pair search reads, in half a cache line: pos, normal, batch-start r2
+    // what the pair search reads, in half a cache line: {pos, batch-start r2} (every candidate), {normal} (those the
+    // radius screen lets through)
     double *c = hps + 8 * i;
-    for (int k = 0; k < 6; k++) c[k] = q[3 + k];
-    c[6] = r2_init;
+    for (int k = 0; k < 3; k++) c[k] = q[3 + k];
+    c[3] = r2_init;
+    for (int k = 0; k < 3; k++) c[4 + k] = q[6 + k];
     c[7] = 0;
     bucket_of[i] = (int)(keys[i] >> 44);
 }
@@ -310,10 +312,11 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
                 // pairs are sorted by (hitpoint, slot) afterwards
                 bool hit0 = false, hit1 = false;
                 if (i < i1) {
-                    const double *h = hps + 8 * (size_t)i;
+                    const double2 *h = reinterpret_cast<const double2 *>(hps) + 4 * (size_t)i;  // 64-byte records
                     const bool two = i + 1 < i1;
-                    const double *g = two ? h + 8 : h;
-                    const V3 d0 = mk(h[0], h[1], h[2]) - P, d1 = mk(g[0], g[1], g[2]) - P;  // the reference's differences
+                    const double2 *g = two ? h + 4 : h;
+                    const double2 h0 = h[0], h1 = h[1], g0 = g[0], g1 = g[1];  // {x, y} {z, r2}
+                    const V3 d0 = mk(h0.x, h0.y, h1.x) - P, d1 = mk(g0.x, g0.y, g1.x) - P;  // the reference's differences
                     // Single-precision screen of the radius test (fewer than 1 in 300 candidates pass it): the fp64
                     // differences rounded to fp32, their squares summed in fp32 -- all terms >= 0, so the result is within
                     // 2^-21 relative of the fp64 sum (plus at most 3 * 2^-150 where a square is subnormal); an overflow means
@@ -323,10 +326,16 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
                     const float ax = (float)d0.x, ay = (float)d0.y, az = (float)d0.z;
                     const float bx = (float)d1.x, by = (float)d1.y, bz = (float)d1.z;
                     const float s0 = ax * ax + ay * ay + az * az, s1 = bx * bx + by * by + bz * bz;
-                    const float lim0 = (float)(h[6] * (1.0 + 0x1p-18)) + 1e-37f, lim1 = (float)(g[6] * (1.0 + 0x1p-18)) + 1e-37f;
+                    const float lim0 = (float)(h1.y * (1.0 + 0x1p-18)) + 1e-37f, lim1 = (float)(g1.y * (1.0 + 0x1p-18)) + 1e-37f;
                     const bool c0 = !(s0 > lim0), c1 = two && !(s1 > lim1);
-                    if (c0) hit0 = (dot(mk(h[3], h[4], h[5]), n) > kEps) && (dot(d0, d0) <= h[6]);  // main.cpp:116, batch-start r2
-                    if (c1) hit1 = (dot(mk(g[3], g[4], g[5]), n) > kEps) && (dot(d1, d1) <= g[6]);
+                    if (c0) {
+                        const double2 h2 = h[2], h3 = h[3];  // {nx, ny} {nz, -}
+                        hit0 = (dot(mk(h2.x, h2.y, h3.x), n) > kEps) && (dot(d0, d0) <= h1.y);  // main.cpp:116, batch-start r2
+                    }
+                    if (c1) {
+                        const double2 g2 = g[2], g3 = g[3];
+                        hit1 = (dot(mk(g2.x, g2.y, g3.x), n) > kEps) && (dot(d1, d1) <= g1.y);
+                    }
                 }
                 const unsigned long long m0 = __ballot(hit0);
                 if (hit0) buf[cnt + (unsigned)__popcll(m0 & lt)] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
@@ -413,7 +422,7 @@ __global__ void photon_apply_kernel(const unsigned long long *__restrict__ keys,
     h[11] = flux.x; h[12] = flux.y; h[13] = flux.z;
     h[14] = r2;
     h[15] = (double)n;
-    hps[8 * i + 6] = r2;  // the next batch's search radius
+    hps[8 * i + 3] = r2;  // the next batch's search radius
 }
 
 // final gather, main.cpp:252-258: per pixel, in table order
