@@ -112,6 +112,9 @@ __device__ __forceinline__ V3 sample_sphere(Stream &rs) {
     }
 }
 
+// whether photon_trace_kernel<false> keeps the wide walk's first stack entries in LDS: 32 KiB per workgroup, taken only
+// while four workgroups (its 4 waves/SIMD) still fit a CU's 160 KiB beside the object list
+__host__ __device__ inline bool photon_lds_stack(const DeviceScene &sc) { return sc.has_wide && sc.n_objs <= 56; }
 // 1. photon paths.  events: count*kSegStride records of 9 doubles; valid: same count of bytes.
 template <bool BEZ>
 __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace_kernel(DeviceScene sc, PhotonArgs pa, double *__restrict__ events,
@@ -126,7 +129,9 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace
     }
     __syncthreads();
     // BEZ: one BezLds per wave behind the object list; the Newton starts continue the photon's own stream
-    const LdsAux aux{BEZ ? reinterpret_cast<volatile BezLds *>(lobjs + sc.n_objs) + (threadIdx.x >> 6) : nullptr, nullptr};
+    LdsAux aux{BEZ ? reinterpret_cast<volatile BezLds *>(lobjs + sc.n_objs) + (threadIdx.x >> 6) : nullptr, nullptr};
+    // without Bezier objects: the first entries of the 4-wide walk's stack live in LDS behind the object list, as in the eye pass
+    if (!BEZ && photon_lds_stack(sc)) aux.wstack = reinterpret_cast<uint2 *>(lobjs + sc.n_objs);
     const int p = blockIdx.x * kThreads + threadIdx.x;
     bool alive = p < pa.count;
     Stream rs(stream_key(pa.seed, (uint64_t)(pa.first + (alive ? p : 0)), 0, 0x70686f74ull));
@@ -490,7 +495,8 @@ void launch_photon_trace(const cgrt_scene *s, const PhotonArgs &pa, double *even
         hipLaunchKernelGGL(photon_trace_kernel<true>, grid, block, lds + (kThreads / 64) * sizeof(BezLds), st, s->dev, pa, events,
                            valid);
     else
-        hipLaunchKernelGGL(photon_trace_kernel<false>, grid, block, lds, st, s->dev, pa, events, valid);
+        hipLaunchKernelGGL(photon_trace_kernel<false>, grid, block,
+                           lds + (photon_lds_stack(s->dev) ? (size_t)kThreads * kWideLdsDepth * sizeof(uint2) : 0), st, s->dev, pa, events, valid);
 }
 
 int sort_pairs32(SortTemp &tmp, unsigned int *kin, unsigned int *kout, unsigned int *vin, unsigned int *vout, size_t n,
