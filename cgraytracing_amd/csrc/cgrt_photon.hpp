@@ -244,6 +244,7 @@ __global__ void event_keys_kernel(const double *__restrict__ events, const unsig
 // the end is reserved with ONE atomic per workgroup, a wave whose buffer fills up earlier reserves for itself.  A global
 // atomic per hit serialises on a single address in L2 -- measured 16 ns each, 13.5 ms per 1.3 M events -- and dominated
 // the whole photon pass; counting first and writing in a second walk (the previous form) paid for every probe twice.
+constexpr int kWalk = 4;      // bucket entries a lane tests per step of the pair search
 constexpr int kPairBuf = 768;  // staged pairs per wave (6 KiB); flushed before an iteration that could overflow it
 
 // `base` is a position in the 64-bit count of ALL pairs the batch produces; only positions below `cap` exist in memory.  The
@@ -306,49 +307,52 @@ __global__ __launch_bounds__(256) void photon_pairs_kernel(const double *__restr
                 ni1 = bstart[b + 1];
             }
             while (__ballot(i < i1) != 0ull) {  // all lanes step through their buckets together
-                if (cnt > (unsigned)(kPairBuf - 128)) {  // the next step could overflow: this wave reserves for itself
+                if (cnt > (unsigned)(kPairBuf - 64 * kWalk)) {  // the next step could overflow: this wave reserves for itself
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(npairs, (unsigned long long)cnt);
                     base = __shfl(base, 0);
                     pairs_flush(buf, cnt, base, keys, vals, cap);
                     cnt = 0;
                 }
-                // two bucket entries per step (their loads in flight together); pair order in the buffer is free, the
+                // kWalk bucket entries per step (their loads in flight together); pair order in the buffer is free, the
                 // pairs are sorted by (hitpoint, slot) afterwards
-                bool hit0 = false, hit1 = false;
-                if (i < i1) {
-                    const double2 *h = reinterpret_cast<const double2 *>(hps) + 4 * (size_t)i;  // 64-byte records
-                    const bool two = i + 1 < i1;
-                    const double2 *g = two ? h + 4 : h;
-                    const double2 h0 = h[0], h1 = h[1], g0 = g[0], g1 = g[1];  // {x, y} {z, r2}
-                    const V3 d0 = mk(h0.x, h0.y, h1.x) - P, d1 = mk(g0.x, g0.y, g1.x) - P;  // the reference's differences
-                    // Single-precision screen of the radius test (fewer than 1 in 300 candidates pass it): the fp64
-                    // differences rounded to fp32, their squares summed in fp32 -- all terms >= 0, so the result is within
-                    // 2^-21 relative of the fp64 sum (plus at most 3 * 2^-150 where a square is subnormal); an overflow means
-                    // a distance no radius reaches, a NaN passes the screen.  The bound is r2 * (1 + 2^-18) converted to
-                    // nearest (>= r2 * (1 + 2^-19)) plus 1e-37, so nothing the exact test accepts is screened out; survivors
-                    // take the exact test.
-                    const float ax = (float)d0.x, ay = (float)d0.y, az = (float)d0.z;
-                    const float bx = (float)d1.x, by = (float)d1.y, bz = (float)d1.z;
-                    const float s0 = ax * ax + ay * ay + az * az, s1 = bx * bx + by * by + bz * bz;
-                    const float lim0 = (float)(h1.y * (1.0 + 0x1p-18)) + 1e-37f, lim1 = (float)(g1.y * (1.0 + 0x1p-18)) + 1e-37f;
-                    const bool c0 = !(s0 > lim0), c1 = two && !(s1 > lim1);
-                    if (c0) {
-                        const double2 h2 = h[2], h3 = h[3];  // {nx, ny} {nz, -}
-                        hit0 = (dot(mk(h2.x, h2.y, h3.x), n) > kEps) && (dot(d0, d0) <= h1.y);  // main.cpp:116, batch-start r2
-                    }
-                    if (c1) {
-                        const double2 g2 = g[2], g3 = g[3];
-                        hit1 = (dot(mk(g2.x, g2.y, g3.x), n) > kEps) && (dot(d1, d1) <= g1.y);
+                bool hit[kWalk];
+                V3 dd[kWalk];
+                double r2s[kWalk];
+                bool cand[kWalk];
+                const double2 *h = reinterpret_cast<const double2 *>(hps) + 4 * (size_t)i;  // 64-byte records
+#pragma unroll
+                for (int u = 0; u < kWalk; u++) {
+                    hit[u] = false;
+                    cand[u] = i + u < i1;
+                    const double2 *g = cand[u] ? h + 4 * u : reinterpret_cast<const double2 *>(hps);
+                    const double2 g0 = g[0], g1 = g[1];  // {x, y} {z, r2}
+                    dd[u] = mk(g0.x, g0.y, g1.x) - P;    // the reference's differences
+                    r2s[u] = g1.y;
+                }
+                // Single-precision screen of the radius test (fewer than 1 in 300 candidates pass it): the fp64
+                // differences rounded to fp32, their squares summed in fp32 -- all terms >= 0, so the result is within
+                // 2^-21 relative of the fp64 sum (plus at most 3 * 2^-150 where a square is subnormal); an overflow means
+                // a distance no radius reaches, a NaN passes the screen.  The bound is r2 * (1 + 2^-18) converted to
+                // nearest (>= r2 * (1 + 2^-19)) plus 1e-37, so nothing the exact test accepts is screened out; survivors
+                // take the exact test.
+#pragma unroll
+                for (int u = 0; u < kWalk; u++) {
+                    const float ax = (float)dd[u].x, ay = (float)dd[u].y, az = (float)dd[u].z;
+                    const float sq = ax * ax + ay * ay + az * az;
+                    const float lim = (float)(r2s[u] * (1.0 + 0x1p-18)) + 1e-37f;
+                    if (cand[u] && !(sq > lim)) {
+                        const double2 g2 = h[4 * u + 2], g3 = h[4 * u + 3];  // {nx, ny} {nz, -}
+                        hit[u] = (dot(mk(g2.x, g2.y, g3.x), n) > kEps) && (dot(dd[u], dd[u]) <= r2s[u]);  // main.cpp:116, batch-start r2
                     }
                 }
-                const unsigned long long m0 = __ballot(hit0);
-                if (hit0) buf[cnt + (unsigned)__popcll(m0 & lt)] = ((unsigned long long)i << 24) | (unsigned long long)s;  // s < 2^24
-                cnt += (unsigned)__popcll(m0);
-                const unsigned long long m1 = __ballot(hit1);
-                if (hit1) buf[cnt + (unsigned)__popcll(m1 & lt)] = ((unsigned long long)(i + 1) << 24) | (unsigned long long)s;
-                cnt += (unsigned)__popcll(m1);
-                i += 2;
+#pragma unroll
+                for (int u = 0; u < kWalk; u++) {
+                    const unsigned long long m = __ballot(hit[u]);
+                    if (hit[u]) buf[cnt + (unsigned)__popcll(m & lt)] = ((unsigned long long)(i + u) << 24) | (unsigned long long)s;  // s < 2^24
+                    cnt += (unsigned)__popcll(m);
+                }
+                i += kWalk;
             }
         }
     }
