@@ -212,11 +212,13 @@ def other_configs(dev_index):
     objs = scenes.planes(tex) + [scenes.TriangleMesh.from_triangles(scenes.dragon_tris(), (0.25, 0.25, 0.5), 0.0, 0.0, 1)]
     sc = cg.Scene(objs, device=dev_index)
     sc.ppm_render(64, 48, 1, scenes.cam_pinhole(), 5, SEED, nphotons=1000)
-    r = sc.ppm_render(1024, 768, 1, scenes.cam_pinhole(), 5, SEED, nphotons=20480000)
+    r_first = sc.ppm_render(1024, 768, 1, scenes.cam_pinhole(), 5, SEED, nphotons=20480000)
+    r = sc.ppm_render(1024, 768, 1, scenes.cam_pinhole(), 5, SEED, nphotons=20480000)  # same call again: buffers of that size warm
     sc.close()
     out["reference main() configuration: 1024x768 spp1, stone.jpg bump floor + dragon, 20 480 000 photons (rows f1/f2)"] = {
         "ms_total": round(sum(r["ms"].values()), 1), "stage_ms": {k: round(v, 2) for k, v in r["ms"].items()},
-        "photons_per_s": round(20480000 / (r["ms"]["photons"] / 1e3)), "photon_events": r["n_events"]}
+        "photons_per_s": round(20480000 / (r["ms"]["photons"] / 1e3)), "photon_events": r["n_events"],
+        "first_call_ms_total": round(sum(r_first["ms"].values()), 1)}
     return out
 
 
