@@ -107,6 +107,14 @@ def lib():
             raise ImportError(
                 "cgraytracing_amd: %s not found -- build the HIP library first "
                 "(make -C cgraytracing_amd/csrc, or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        # Load order matters where PyTorch is in the process: libtorch_hip needs "libamdhip64.so" (its bundled copy, found by
+        # RPATH) while libcgrt.so needs "libamdhip64.so.7".  With torch first, our NEEDED entry matches the SONAME of the copy
+        # already loaded and the process has ONE HIP runtime; with libcgrt.so first, torch's name matches nothing loaded, a
+        # second runtime comes in and one of the two then finds "no ROCm-capable device".  So torch, when importable, goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported

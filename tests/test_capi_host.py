@@ -362,3 +362,16 @@ def test_device_hierarchy_structure():
     sc = Scene(scenes.planes(scenes.stone_small_texture(True)), commit=False)
     assert sc.bvh_dump(0)[0].shape[1] == 0  # opaque bump floor: height-field walk, no hierarchy
     sc.close()
+
+
+def test_library_load_puts_torch_first():
+    """One HIP runtime per process: libtorch_hip asks for "libamdhip64.so" (its bundled copy), libcgrt.so for
+    "libamdhip64.so.7"; only with torch loaded FIRST does our NEEDED entry resolve to the copy already in the process.
+    build() followed by smoke() in one process (library first, torch later) found "no ROCm-capable device" before
+    _capi.lib() imported torch itself.  Checked here without a GPU: loading the library leaves torch imported."""
+    import subprocess
+    import sys
+    code = ("import sys; from cgraytracing_amd import _capi; assert 'torch' not in sys.modules; _capi.lib(); "
+            "assert 'torch' in sys.modules; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
