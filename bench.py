@@ -269,19 +269,36 @@ def self_launch(n, argv):
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+
+    def stop_rest(grace=5.0):
+        """terminate exactly the children we started that still run; kill the ones that ignore it"""
+        live = [q for q in procs if q.poll() is None]
+        for q in live:
+            q.terminate()
+        t_end = time.monotonic() + grace
+        for q in live:
+            try:
+                q.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
+    # All children are watched together: a rank that dies first (out of memory, RCCL init failure) would otherwise leave
+    # the others waiting in a collective -- and this parent waiting on rank 0 -- until the backend's own timeout.
     worst = 0
     try:
-        for p in procs:
-            rc = p.wait()
-            worst = worst or rc
-            if rc != 0:  # a dead rank would leave the others waiting in a collective: stop exactly the ones we started
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                worst = bad[0]
+                stop_rest()
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.05)
     except KeyboardInterrupt:
-        for q in procs:
-            if q.poll() is None:
-                q.terminate()
+        stop_rest()
         raise
     return worst
 
@@ -313,6 +330,8 @@ def main():
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     n = world
+    if os.environ.get("CGRT_BENCH_FAIL_RANK") == str(rank):  # test hook (tests/test_bench_launch.py): this rank dies before rendezvous
+        sys.exit(7)
     cfg = resolve(args, n)
     steps = args.steps if args.steps is not None else cfg["steps"]
     warmup = args.warmup if args.warmup is not None else cfg["warmup"]
@@ -446,6 +465,12 @@ def main():
         else:
             # algorithmic HBM bytes of one launch on one GPU: fp32 RGB store + scene read once
             alg_bytes = 12 * W * rows_local + stats["scene_bytes_fp64"]
+            if not kern_ms:  # --steps 0: nothing was timed
+                print(json.dumps(dict(line, value=None, roofline=None)), flush=True)
+                if n > 1:
+                    dist.barrier()
+                    dist.destroy_process_group()
+                return
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
             traffic_prof, valu_prof = profile_replay(cfg, n)
             line["roofline"] = {

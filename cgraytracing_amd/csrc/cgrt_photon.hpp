@@ -15,12 +15,12 @@
 //                              cells hash to (hash.h:35-37), collisions included -- and emits (hitpoint, order)
 //                              pairs that pass the static tests (normal, distance against the radius the hitpoint
 //                              had at the start of the batch, which only shrinks);
-//   3. radix sort of the pairs by (hitpoint, order)                                     [hipcub]
+//   3. radix sort of the pairs by (hitpoint, order)                                     [rocprim]
 //   4. photon_apply_kernel   : one lane per hitpoint; replays its events in order with the reference's update
 //                              (main.cpp:116-122), re-checking the distance against the current radius.
 // Hitpoints are kept sorted by (bucket, emission order) = the reference's table order, which is also the order of
 // its final gather (main.cpp:252-258); the image is summed per pixel in that order.
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -486,9 +486,9 @@ struct SortTemp {
 int sort_pairs(SortTemp &tmp, unsigned long long *kin, unsigned long long *kout, unsigned int *vin, unsigned int *vout, size_t n,
                int end_bit = 64, hipStream_t st = 0) {
     size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, st));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, n, 0u, (unsigned)end_bit, st));
     HIP_TRY(tmp.need(tmp_bytes));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, st));
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.buf.p, tmp_bytes, kin, kout, vin, vout, n, 0u, (unsigned)end_bit, st));
     return CGRT_OK;
 }
 
@@ -506,9 +506,9 @@ void launch_photon_trace(const cgrt_scene *s, const PhotonArgs &pa, double *even
 int sort_pairs32(SortTemp &tmp, unsigned int *kin, unsigned int *kout, unsigned int *vin, unsigned int *vout, size_t n,
                  hipStream_t st = 0) {
     size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, n, 0u, 32u, st));
     HIP_TRY(tmp.need(tmp_bytes));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, tmp_bytes, kin, kout, vin, vout, (int)n, 0, 32, st));
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.buf.p, tmp_bytes, kin, kout, vin, vout, n, 0u, 32u, st));
     return CGRT_OK;
 }
 

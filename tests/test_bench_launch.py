@@ -70,3 +70,17 @@ def test_external_launcher_env_is_respected():
     noise = lambda t: [ln for ln in t.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
     assert noise(outs[1][0]) == []
     assert json.loads(noise(outs[0][0])[0])["frame_rows_ok"] is True
+
+
+def test_dead_rank_stops_the_launch_quickly():
+    """a rank that exits non-zero first must not leave the parent waiting on rank 0 (which sits in the rendezvous /
+    a collective until the backend's timeout): the parent polls all children, stops the rest and returns non-zero at once."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CGRT_BENCH_FAIL_RANK"] = "1"
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    dt = time.monotonic() - t0
+    assert p.returncode == 7, (p.returncode, p.stdout, p.stderr)
+    assert dt < 60, dt  # import torch + rendezvous start dominate; the gloo rendezvous timeout would be 30 min
