@@ -53,6 +53,13 @@ class SceneStats(C.Structure):
                 ("n_nodes", C.c_int64), ("device_bytes", C.c_int64), ("scene_bytes_fp64", C.c_int64)]
 
 
+class BuildInfo(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n_device_trees", C.c_int32), ("ms_host_build", C.c_double),
+                ("ms_device_build", C.c_double), ("ms_commit", C.c_double)]
+
+
+BUILD_HOST, BUILD_DEVICE = 0, 1
+
 # every symbol include/cgrt.h declares, with its signature
 _DP = C.POINTER(C.c_double)
 SIGNATURES = {
@@ -60,6 +67,8 @@ SIGNATURES = {
     "cgrt_last_error": (C.c_char_p, []),
     "cgrt_scene_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cgrt_scene_destroy": (None, [C.c_void_p]),
+    "cgrt_scene_set_build": (C.c_int, [C.c_void_p, C.c_int]),
+    "cgrt_scene_build_info": (C.c_int, [C.c_void_p, C.POINTER(BuildInfo)]),
     "cgrt_scene_add_sphere": (C.c_int, [C.c_void_p, _DP, C.c_double, _DP, C.c_double, C.c_double]),
     "cgrt_scene_add_texture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _DP, _DP, C.c_double,
                                          C.c_double, C.c_int]),

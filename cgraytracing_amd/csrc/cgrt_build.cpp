@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <future>
 #include <thread>
 #include <unordered_map>
@@ -555,6 +556,19 @@ void HostTree::build_hfield(int nx, int nz, double x0, double z0, double hx, dou
     is_hfield = true;
 }
 
+int64_t ref_node_count(int64_t n) {
+    return n < kMinKd ? 1 : 1 + ref_node_count(n / 2) + ref_node_count(n - n / 2);
+}
+
+namespace {
+struct BuildTimer {  // adds the enclosing scope's wall-clock to HostScene::host_build_ms
+    double &acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit BuildTimer(double &a) : acc(a) {}
+    ~BuildTimer() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 bool load_mesh_file(const char *file, double a, const double b[3], int type, std::vector<double> &tri9,
                     std::string &err) {
     tri9.clear();
@@ -643,6 +657,30 @@ int HostScene::add_plane(const double p[3], const double n[3], const double sc[3
         // split into triangles (a,b,c) and (d,b,c); heights 0.5*(1-exp(-3.3*luma)) (texture.h:28-35).
         const HostTexture &tx = textures[tex];
         const int R = tx.rows, C = tx.cols, step = 3;
+        const bool grid_ok = C / step - 1 >= 1 && R / step - 1 >= 1 && tx.lenx * step / C > 0 && tx.leny * step / R > 0 &&
+                             std::isfinite(tx.lenx * step / C) && std::isfinite(tx.leny * step / R) && std::isfinite(tx.p[0]) &&
+                             std::isfinite(tx.p[2]);
+        if (build_mode == 1 && transp < kEps && grid_ok) {
+            // row f3: heights, vertices and grid cells are generated on the device at commit (cgrt_devbuild.hpp)
+            HostTree tree;
+            tree.dev_kind = 2;
+            tree.dev_tex = tex;
+            tree.dev_plane_y = p[1];
+            tree.dev_ntri = 2 * (int64_t)(C / step - 1) * (R / step - 1);
+            tree.is_hfield = true;
+            tree.hfield.cell_begin = 0;
+            tree.hfield.nx = C / step - 1;
+            tree.hfield.nz = R / step - 1;
+            tree.hfield.x0 = tx.p[0];
+            tree.hfield.z0 = tx.p[2];
+            tree.hfield.hx = tx.lenx * step / C;
+            tree.hfield.hz = tx.leny * step / R;
+            trees.push_back(std::move(tree));
+            o.tree = (int)trees.size() - 1;
+            objs.push_back(o);
+            return (int)objs.size() - 1;
+        }
+        BuildTimer timer(host_build_ms);
         std::vector<double> height((size_t)R * C);
         for (int i = 0; i < R; i++)
             for (int j = 0; j < C; j++) {
@@ -731,6 +769,20 @@ int HostScene::add_mesh_triangles(const double *tri9, int ntri, const double sc[
     o.aux = type;
     HostTree tree;
     tree.tri9.assign(tri9, tri9 + (size_t)ntri * 9);
+    if (build_mode == 1 && transp < kEps && ntri > 0) {
+        // row f3: hierarchy, bounding sphere and cover spheres are built on the device at commit (cgrt_devbuild.hpp)
+        tree.dev_kind = 1;
+        tree.dev_ntri = ntri;
+        tree.dev_obj = (int)objs.size();
+        tree.tri_level = true;
+        o.a[0] = o.a[1] = o.a[2] = 0;
+        o.s0 = -1.0;  // until the commit has the sphere
+        trees.push_back(std::move(tree));
+        o.tree = (int)trees.size() - 1;
+        objs.push_back(o);
+        return (int)objs.size() - 1;
+    }
+    BuildTimer timer(host_build_ms);
     tree.build(transp < kEps);  // objects.h:402; an opaque owner gets the triangle-level hierarchy
     {   // bounding sphere of the mesh (a = centre, s0 = radius^2): the scene walk's division-free early-out.  A triangle can
         // only be hit at one of its own points, so a sphere around every vertex (plus 1e-3, far above the triangle test's

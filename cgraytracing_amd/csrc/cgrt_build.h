@@ -41,7 +41,22 @@ struct HostTree {
     std::vector<HCellRec> hcells;
     void build(bool opaque = false, bool with_bvh = true);
     void build_hfield(int nx, int nz, double x0, double z0, double hx, double hz);
+    // Row f3 (cgrt_devbuild.hpp): an opaque owner's structure is built on the device at commit; nothing above is filled on the
+    // host then except tri9 (a mesh's input triangles).  dev_kind: 0 = host build, 1 = mesh (4-wide triangle-level hierarchy),
+    // 2 = bump floor (grid cells generated from the texture bytes).
+    int dev_kind = 0;
+    int64_t dev_ntri = 0;       // triangles the device build will produce / was given
+    int dev_tex = -1;           // bump floor: texture index
+    double dev_plane_y = 0;     // bump floor: the plane's y (objects.h:489-492)
+    int dev_obj = -1;           // mesh: the owning object (its bounding sphere is computed by the device build)
+    size_t dev_cover_at = 0;    // mesh: where its cover spheres go in HostScene::cover (appended at commit)
+    // filled by the commit for the verification dumps (cgrt_scene_wide_dump on a device-built tree reads the device arrays)
+    int32_t dev_nwide = 0;
+    bool dev_balanced = false;
 };
+// nodes of the reference's tree over n triangles (objects.h:217-267: leaf below 10, halves n/2 and n - n/2): what
+// cgrt_scene_stats reports for a tree that was never built on the host
+int64_t ref_node_count(int64_t n);
 
 struct HostTexture {
     std::vector<uint8_t> rgb;
@@ -58,6 +73,8 @@ struct HostScene {
     std::vector<BezSlabRec> bez_slabs;  // kBezSlabs per Bezier object (see BezSlabRec)
     std::vector<double> cover;  // (cx, cy, cz, r) spheres that together contain every mesh triangle (classify_kernel)
     std::string error;
+    int build_mode = 0;      // CGRT_BUILD_HOST / CGRT_BUILD_DEVICE (cgrt.h): where opaque owners' structures are built
+    double host_build_ms = 0;  // wall-clock spent in HostTree::build* by the add_* calls
 
     int add_sphere(const double c[3], double r, const double sc[3], double refl, double transp);
     int add_texture(const uint8_t *rgb, int rows, int cols, const double n[3], const double p[3], double lx,

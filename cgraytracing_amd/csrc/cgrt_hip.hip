@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +57,8 @@ struct cgrt_scene {
     // second stream + fork/join events for the light-tile launch that runs beside the full one (created at commit)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    cgrt_build_info build_info{};  // filled by cgrt_scene_commit
+    std::vector<TreeRec> tree_recs;  // host copy of dev.trees (where a device-built tree's records live)
 };
 
 static thread_local std::string g_err;
@@ -105,9 +108,9 @@ struct DevBuf {  // RAII for device temporaries: freed on every return path
 };
 
 template <class T>
-static int upload(cgrt_scene *s, const std::vector<T> &v, const T **out) {
+static int upload(cgrt_scene *s, const std::vector<T> &v, const T **out, size_t extra = 0) {  // extra: records of room behind v
     *out = nullptr;
-    size_t bytes = v.size() * sizeof(T);
+    size_t bytes = (v.size() + extra) * sizeof(T);
     if (bytes == 0) bytes = sizeof(T);  // keep pointers non-null
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
@@ -118,6 +121,8 @@ static int upload(cgrt_scene *s, const std::vector<T> &v, const T **out) {
     return CGRT_OK;
 }
 
+#include "cgrt_devbuild.hpp"
+
 extern "C" {
 
 int cgrt_version(void) { return CGRT_VERSION; }
@@ -126,7 +131,10 @@ const char *cgrt_last_error(void) { return g_err.c_str(); }
 int cgrt_scene_create(cgrt_scene **out) {
     if (!out) return fail(CGRT_ERR_INVALID, "cgrt_scene_create: null out");
     *out = new (std::nothrow) cgrt_scene();
-    return *out ? CGRT_OK : fail(CGRT_ERR_INVALID, "out of memory");
+    if (!*out) return fail(CGRT_ERR_INVALID, "out of memory");
+    // CGRT_BUILD=device: the default of cgrt_scene_set_build for scenes created from now on (row f3)
+    if (const char *e = std::getenv("CGRT_BUILD")) (*out)->host.build_mode = std::strcmp(e, "device") == 0 ? CGRT_BUILD_DEVICE : CGRT_BUILD_HOST;
+    return CGRT_OK;
 }
 
 void cgrt_scene_destroy(cgrt_scene *s) {
@@ -153,6 +161,20 @@ static int added(cgrt_scene *s, int r) {
     if (r < 0) return fail(CGRT_ERR_INVALID, s->host.error);
     if ((int)s->host.objs.size() > kMaxObjs) return fail(CGRT_ERR_LIMIT, "more than 96 top-level objects");
     return r;
+}
+
+int cgrt_scene_set_build(cgrt_scene *s, int mode) {
+    NEED_OPEN(s);
+    if (mode != CGRT_BUILD_HOST && mode != CGRT_BUILD_DEVICE) return fail(CGRT_ERR_INVALID, "unknown build mode");
+    s->host.build_mode = mode;
+    return CGRT_OK;
+}
+int cgrt_scene_build_info(const cgrt_scene *s, cgrt_build_info *out) {
+    if (!s || !out) return fail(CGRT_ERR_INVALID, "null argument");
+    *out = s->build_info;
+    out->mode = s->host.build_mode;
+    out->ms_host_build = s->host.host_build_ms;
+    return CGRT_OK;
 }
 
 int cgrt_scene_add_sphere(cgrt_scene *s, const double c[3], double r, const double sc[3], double refl, double transp) {
@@ -212,6 +234,10 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     ON_DEVICE(device);
     s->device = device;
     HostScene &H = s->host;
+    const auto t_commit0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     // flatten trees
     std::vector<NodeRec> nodes;
     std::vector<TriRec> tris;
@@ -221,8 +247,15 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     std::vector<OTriRec> otris;
     std::vector<NodeRec> tboxes;
     std::vector<WideNodeRec> wnodes;
+    // row f3: records a device build will produce go BEHIND the host-built ones of the same array (room only, no host copy)
+    size_t dev_tris = 0, dev_otris = 0, dev_wnodes = 0, dev_hcells = 0;
     for (auto &t : H.trees) {
         TreeRec tr;
+        if (t.dev_kind) {  // offsets are assigned once the host parts' sizes are known (second loop below)
+            std::memset(&tr, 0, sizeof(tr));
+            trees.push_back(tr);
+            continue;
+        }
         tr.node_begin = (int64_t)nodes.size();
         tr.tri_begin = (int64_t)tris.size();
         // CGRT_TREE=ref (measurement aid): traverse the reference's own inner nodes instead of the SAH hierarchy
@@ -277,25 +310,92 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         texels.insert(texels.end(), t.rgb.begin(), t.rgb.end());
         texs.push_back(tr);
     }
+    // device-built trees: their place behind the host-built records
+    int n_dev_trees = 0;
+    for (size_t ti = 0; ti < H.trees.size(); ti++) {
+        const HostTree &t = H.trees[ti];
+        if (!t.dev_kind) continue;
+        n_dev_trees++;
+        TreeRec &tr = trees[ti];
+        tr.hfield = -1;
+        tr.noct = 1;
+        tr.ntris = (int32_t)t.dev_ntri;
+        tr.node_begin = (int64_t)nodes.size();
+        tr.tbox_begin = (int64_t)tboxes.size();
+        tr.tri_begin = (int64_t)(tris.size() + dev_tris);
+        tr.otri_begin = (int64_t)(otris.size() + dev_otris);
+        tr.wnode_begin = (int64_t)(wnodes.size() + dev_wnodes);
+        dev_tris += (size_t)t.dev_ntri;
+        if (t.dev_kind == 1) {  // opaque mesh: triangle-level hierarchy, 4-wide (nwide is known after the build)
+            tr.tri_level = 1;
+            dev_otris += (size_t)t.dev_ntri;
+            dev_wnodes += (size_t)t.dev_ntri;
+        } else {  // bump floor: grid cells
+            HFieldRec hf = t.hfield;
+            hf.cell_begin = (int64_t)(hcells.size() + dev_hcells);
+            dev_hcells += (size_t)hf.nx * (size_t)hf.nz;
+            tr.hfield = (int32_t)hfields.size();
+            hfields.push_back(hf);  // ylo / yhi come from the build
+        }
+    }
     DeviceScene d{};
     int rc = CGRT_OK;
+    double ms_device_build = 0;
+    const size_t cover_host = H.cover.size();  // device builds append their cover spheres; a failed commit takes them back
     // a commit that fails part-way leaves nothing behind: the scene stays open and a later commit starts from scratch
     auto all_uploads = [&]() -> int {
-        if ((rc = upload(s, H.objs, &d.objs))) return rc;
+        // the large arrays first: the device builds write into the room behind the host-built records
         if ((rc = upload(s, nodes, &d.nodes))) return rc;
-        if ((rc = upload(s, tris, &d.tris))) return rc;
+        if ((rc = upload(s, tris, &d.tris, dev_tris))) return rc;
+        if ((rc = upload(s, texels, &d.texels))) return rc;
+        if ((rc = upload(s, hcells, &d.hcells, dev_hcells))) return rc;
+        if ((rc = upload(s, otris, &d.otris, dev_otris))) return rc;
+        if ((rc = upload(s, tboxes, &d.tboxes))) return rc;
+        if ((rc = upload(s, wnodes, &d.wnodes, dev_wnodes))) return rc;
+        if (n_dev_trees > 0) {
+            const auto t_build0 = std::chrono::steady_clock::now();
+            for (size_t ti = 0; ti < H.trees.size(); ti++) {
+                HostTree &t = H.trees[ti];
+                TreeRec &tr = trees[ti];
+                if (t.dev_kind == 2) {
+                    const HostTexture &tx = H.textures[(size_t)t.dev_tex];
+                    HFieldRec &hf = hfields[(size_t)tr.hfield];
+                    devbuild::BumpResult br;
+                    if ((rc = devbuild::build_bump_floor(d.texels + texs[(size_t)t.dev_tex].texel_begin, tx.rows, tx.cols, tx.p, tx.lenx,
+                                                         tx.leny, t.dev_plane_y, const_cast<HCellRec *>(d.hcells) + hf.cell_begin,
+                                                         const_cast<TriRec *>(d.tris) + tr.tri_begin, br)))
+                        return rc;
+                    hf.ylo = br.ylo;
+                    hf.yhi = br.yhi;
+                    t.hfield.ylo = br.ylo;
+                    t.hfield.yhi = br.yhi;
+                } else if (t.dev_kind == 1) {
+                    devbuild::MeshResult mr;
+                    if ((rc = devbuild::build_mesh_hierarchy(t.tri9.data(), (int)t.dev_ntri, const_cast<TriRec *>(d.tris) + tr.tri_begin,
+                                                             const_cast<OTriRec *>(d.otris) + tr.otri_begin,
+                                                             const_cast<WideNodeRec *>(d.wnodes) + tr.wnode_begin, mr)))
+                        return rc;
+                    tr.nwide = mr.nwide;
+                    t.dev_nwide = mr.nwide;
+                    t.wide_stack = mr.stack_need;
+                    t.dev_balanced = mr.balanced;
+                    ObjRec &ob = H.objs[(size_t)t.dev_obj];
+                    for (int k = 0; k < 3; k++) ob.a[k] = mr.centre[k];
+                    ob.s0 = mr.r2;
+                    t.dev_cover_at = H.cover.size();
+                    H.cover.insert(H.cover.end(), mr.cover.begin(), mr.cover.end());
+                }
+            }
+            ms_device_build = ms_since(t_build0);
+        }
+        if ((rc = upload(s, H.objs, &d.objs))) return rc;
         if ((rc = upload(s, trees, &d.trees))) return rc;
         if ((rc = upload(s, texs, &d.texs))) return rc;
-        if ((rc = upload(s, texels, &d.texels))) return rc;
         if ((rc = upload(s, H.beziers, &d.beziers))) return rc;
         if ((rc = upload(s, H.bez_slabs, &d.bez_slabs))) return rc;
         // CGRT_NO_BEZIER_CULL=1 (measurement / test aid, read at every commit): run every solve of every ray that enters the box
         if (const char *e = std::getenv("CGRT_NO_BEZIER_CULL")) if (*e && *e != '0') d.bez_slabs = nullptr;
         if ((rc = upload(s, hfields, &d.hfields))) return rc;
-        if ((rc = upload(s, hcells, &d.hcells))) return rc;
-        if ((rc = upload(s, otris, &d.otris))) return rc;
-        if ((rc = upload(s, tboxes, &d.tboxes))) return rc;
-        if ((rc = upload(s, wnodes, &d.wnodes))) return rc;
         if ((rc = upload(s, H.cover, &d.cover))) return rc;
         return CGRT_OK;
     };
@@ -304,6 +404,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         s->allocs.clear();
         s->device_bytes = 0;
         s->device = -1;
+        H.cover.resize(cover_host);
         return rc;
     }
     d.n_objs = (int32_t)H.objs.size();
@@ -311,7 +412,9 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     d.n_texs = (int32_t)texs.size();
     d.n_beziers = (int32_t)H.beziers.size();
     d.n_cover = (int32_t)(H.cover.size() / 4);
-    d.has_wide = wnodes.empty() ? 0 : 1;
+    d.has_wide = 0;
+    for (const TreeRec &tr : trees)
+        if (tr.nwide > 0) d.has_wide = 1;
     d.has_mesh = trees.empty() ? 0 : 1;
     d.has_bezier = H.beziers.empty() ? 0 : 1;
     d.cached_tree = -1;
@@ -353,6 +456,10 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     }
     s->dev = d;
     s->committed = true;
+    s->tree_recs = trees;
+    s->build_info.n_device_trees = n_dev_trees;
+    s->build_info.ms_device_build = ms_device_build;
+    s->build_info.ms_commit = ms_since(t_commit0);
     return CGRT_OK;
 }
 
@@ -371,6 +478,11 @@ int cgrt_scene_get_stats(const cgrt_scene *s, cgrt_scene_stats *out) {
     out->n_textures = (int32_t)H.textures.size();
     out->n_trees = (int32_t)H.trees.size();
     for (auto &t : H.trees) {
+        if (t.dev_kind) {  // never built on the host: the counts the reference's tree over these triangles would have
+            out->n_triangles += t.dev_ntri;
+            out->n_nodes += ref_node_count(t.dev_ntri);
+            continue;
+        }
         out->n_triangles += (int64_t)t.tris.size();
         out->n_nodes += (int64_t)t.nodes.size();
     }
@@ -387,7 +499,7 @@ int cgrt_scene_tree_sizes(const cgrt_scene *s, int t, int32_t *nnodes, int32_t *
     const HostTree &T = s->host.trees[t];
     if (nnodes) *nnodes = (int32_t)T.nodes.size();  // the reference's tree (fingerprints); the device hierarchy is T.bvh
     if (nleaftris) *nleaftris = (int32_t)T.leaf_ids.size();
-    if (ntris) *ntris = (int32_t)(T.tri9.size() / 9);
+    if (ntris) *ntris = T.dev_kind ? (int32_t)T.dev_ntri : (int32_t)(T.tri9.size() / 9);  // device-built: no reference tree exists (0 nodes)
     return CGRT_OK;
 }
 int cgrt_scene_bvh_dump(const cgrt_scene *s, int t, int32_t *nnodes, float *box6, int32_t *skip_leaf2) {
@@ -411,10 +523,19 @@ int cgrt_scene_bvh_dump(const cgrt_scene *s, int t, int32_t *nnodes, float *box6
 int cgrt_scene_wide_dump(const cgrt_scene *s, int t, int32_t *nwide, int32_t *stack_need, float *box24, int32_t *ref4) {
     if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
     const HostTree &T = s->host.trees[t];
-    if (nwide) *nwide = (int32_t)T.wide.size();
+    std::vector<WideNodeRec> from_device;
+    if (T.dev_kind == 1 && s->committed && (box24 || ref4)) {  // built on the device (row f3): read the records back
+        ON_DEVICE(s->device);
+        from_device.resize((size_t)T.dev_nwide);
+        if (T.dev_nwide > 0)
+            HIP_TRY(hipMemcpy(from_device.data(), s->dev.wnodes + s->tree_recs[(size_t)t].wnode_begin,
+                              from_device.size() * sizeof(WideNodeRec), hipMemcpyDeviceToHost));
+    }
+    const std::vector<WideNodeRec> &wide = T.dev_kind == 1 ? from_device : T.wide;
+    if (nwide) *nwide = T.dev_kind == 1 ? T.dev_nwide : (int32_t)T.wide.size();
     if (stack_need) *stack_need = T.wide_stack;
-    for (size_t i = 0; i < T.wide.size(); i++) {
-        const WideNodeRec &w = T.wide[i];
+    for (size_t i = 0; i < wide.size(); i++) {
+        const WideNodeRec &w = wide[i];
         for (int k = 0; k < 4; k++) {
             if (box24) {
                 float *q = box24 + (4 * i + (size_t)k) * 6;
@@ -430,6 +551,14 @@ int cgrt_scene_bvh_order(const cgrt_scene *s, int t, int32_t *tri_level, int32_t
     if (!s || t < 0 || t >= (int)s->host.trees.size()) return fail(CGRT_ERR_INVALID, "bad tree index");
     const HostTree &T = s->host.trees[t];
     if (tri_level) *tri_level = T.tri_level ? 1 : 0;
+    if (order && T.dev_kind == 1 && s->committed) {  // built on the device: k = the triangle's construction index
+        ON_DEVICE(s->device);
+        std::vector<OTriRec> ot((size_t)T.dev_ntri);
+        if (!ot.empty())
+            HIP_TRY(hipMemcpy(ot.data(), s->dev.otris + s->tree_recs[(size_t)t].otri_begin, ot.size() * sizeof(OTriRec), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < ot.size(); j++) order[j] = ot[j].k;
+        return CGRT_OK;
+    }
     if (order)
         for (size_t j = 0; j < T.otris.size(); j++) order[j] = T.otris[j].k;
     return CGRT_OK;

@@ -22,10 +22,14 @@ class Scene:
     """Owns a cgrt_scene handle.  `objs` order is the reference's `objs` order.  commit=False keeps the scene
     on the host only (mesh loading / tree build can then be inspected without a GPU)."""
 
-    def __init__(self, objs, device=0, commit=True):
+    def __init__(self, objs, device=0, commit=True, build=None):
+        """build: None (the library's default: host, or what CGRT_BUILD says), "host" or "device" (cgrt_scene_set_build: opaque
+        owners' structures built on the GPU at commit; tolerance-class parity, see include/cgrt.h)."""
         L = _capi.lib()
         h = C.c_void_p()
         check(L.cgrt_scene_create(C.byref(h)))
+        if build is not None:
+            check(L.cgrt_scene_set_build(h, {"host": _capi.BUILD_HOST, "device": _capi.BUILD_DEVICE}[build]))
         self._h = h
         self._L = L
         self.device = int(device)
@@ -91,6 +95,11 @@ class Scene:
         st = _capi.SceneStats()
         check(self._L.cgrt_scene_get_stats(self._h, C.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
+
+    def build_info(self):
+        bi = _capi.BuildInfo()
+        check(self._L.cgrt_scene_build_info(self._h, C.byref(bi)))
+        return {f: getattr(bi, f) for f, _ in bi._fields_}
 
     def tree_dump(self, t=0):
         nn, nl, nt = C.c_int32(), C.c_int32(), C.c_int32()

@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define CGRT_VERSION 111 /* 110: cgrt_photons.initial_radius / .pair_cap, cgrt_ppm_result.n_batch_halvings,
-                            cgrt_surface_colors, cgrt_trace_grid_variant; 111: cgrt_scene_wide_dump */
+#define CGRT_VERSION 112 /* 110: cgrt_photons.initial_radius / .pair_cap, cgrt_ppm_result.n_batch_halvings,
+                            cgrt_surface_colors, cgrt_trace_grid_variant; 111: cgrt_scene_wide_dump;
+                            112: cgrt_scene_set_build, cgrt_scene_build_info (row f3: structures built on the device) */
 
 enum {
     CGRT_OK = 0,
@@ -120,6 +121,32 @@ const char *cgrt_last_error(void);
  *      earlier object wins (main.cpp:57). */
 int cgrt_scene_create(cgrt_scene **out);
 void cgrt_scene_destroy(cgrt_scene *s);
+
+/* ---- row f3 of SURVEY.md section 8: WHERE the acceleration structures of OPAQUE owners are built -------------------------
+ * CGRT_BUILD_HOST (default): KDTree::buildKdTree's leaf order (objects.h:217-267, the same std::sort over the same
+ * sequence), the bump mesh of objects.h:480-504 and the height field of texture.h:19-38 are produced on the host by the add_*
+ * calls, bit for bit the reference's; the device hierarchies are derived from them.
+ * CGRT_BUILD_DEVICE: for objects added AFTER this call whose transparency is < 1e-4, cgrt_scene_commit builds them on the
+ * GPU instead -- a bump floor's heights, vertices and grid cells from the texture bytes; an opaque mesh's triangle-level
+ * hierarchy from the triangle soup (Morton codes, radix sort, binary radix tree, 4-wide collapse), its bounding and cover
+ * spheres.  Transparent owners keep the host build (their normals depend on the reference's leaf ORDER, quirk Q5).
+ * Parity class of this mode: tolerance, not bit-exact -- every ray with a unique nearest hit gets the same hit, bit for
+ * bit; exact ties (a ray through a shared edge or vertex) go to the lower construction index instead of the reference's
+ * leaf-order rule, and heights use a correctly rounded exp where the reference's libm is only within 0.52 ulp.  The
+ * verification dumps that describe the reference's tree (cgrt_scene_tree_dump, cgrt_scene_bvh_dump) are empty for a
+ * device-built tree; cgrt_scene_wide_dump / cgrt_scene_bvh_order read the device's records back.
+ * The environment variable CGRT_BUILD=device makes CGRT_BUILD_DEVICE the default of scenes created afterwards. */
+enum { CGRT_BUILD_HOST = 0, CGRT_BUILD_DEVICE = 1 };
+int cgrt_scene_set_build(cgrt_scene *s, int mode);
+
+typedef struct cgrt_build_info {
+    int32_t mode;            /* CGRT_BUILD_*                                                                              */
+    int32_t n_device_trees;  /* trees the commit built on the device                                                      */
+    double ms_host_build;    /* wall-clock the add_* calls spent building trees / bump meshes on the host                 */
+    double ms_device_build;  /* wall-clock of the device builds inside cgrt_scene_commit (uploads of their inputs included) */
+    double ms_commit;        /* wall-clock of cgrt_scene_commit as a whole                                                */
+} cgrt_build_info;
+int cgrt_scene_build_info(const cgrt_scene *s, cgrt_build_info *out);
 
 /* Sphere(c, r, sc, refl, transp)                                                   objects.h:28-38 */
 int cgrt_scene_add_sphere(cgrt_scene *s, const double c[3], double r, const double sc[3], double refl, double transp);

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libcgrt.so does not export %s" % name
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
-    assert _capi.lib().cgrt_version() == 111
+    assert _capi.lib().cgrt_version() == 112
 
 
 def test_struct_layouts_match_header():
