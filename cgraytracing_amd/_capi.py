@@ -85,6 +85,8 @@ SIGNATURES = {
     "cgrt_scene_tree_dump": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cgrt_trace_grid": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    "cgrt_unpermute_stripes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
     "cgrt_trace_grid_host": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "cgrt_trace_grid_hitpoints": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Grid), C.c_void_p, C.c_uint64,

@@ -54,6 +54,8 @@ struct cgrt_scene {
     // (launches on one handle are ordered by the caller: cgrt.h, "Threading")
     mutable void *scratch = nullptr;
     mutable size_t scratch_bytes = 0;
+    mutable size_t scratch_refused = 0;  // smallest scratch size this device has refused (0: none yet): not asked for again
+    size_t mem_total = 0;                // memory of the scene's device (read at commit; bounds the deferred-value budget)
     // second stream + fork/join events for the light-tile launch that runs beside the full one (created at commit)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -457,6 +459,10 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     s->dev = d;
     s->committed = true;
     s->tree_recs = trees;
+    {
+        size_t fr = 0, tot = 0;
+        s->mem_total = hipMemGetInfo(&fr, &tot) == hipSuccess ? tot : ((size_t)32 << 30);
+    }
     s->build_info.n_device_trees = n_dev_trees;
     s->build_info.ms_device_build = ms_device_build;
     s->build_info.ms_commit = ms_since(t_commit0);
@@ -489,7 +495,7 @@ int cgrt_scene_get_stats(const cgrt_scene *s, cgrt_scene_stats *out) {
     bytes += 56 * out->n_nodes + 72 * out->n_triangles;
     for (auto &t : H.textures) bytes += 3 * (int64_t)t.rows * t.cols;
     out->scene_bytes_fp64 = bytes;
-    out->device_bytes = s->device_bytes;
+    out->device_bytes = s->device_bytes + (int64_t)s->scratch_bytes;  // uploaded scene + the handle's launch scratch
     out->committed = s->committed ? 1 : 0;
     return CGRT_OK;
 }
@@ -649,9 +655,8 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.lens_radius = cam->lens_radius;
 
     g.xcd_tiles = (s->dev.has_mesh && !s->dev.has_bezier) ? 1 : 0;
-    // Split a tile's samples over several workgroups (CGRT_GRID_SPLIT_SAMPLES, and always with a Bezier object: the few
-    // tiles over it carry nearly all the work -- measured 1.2 of 3 wave slots per SIMD occupied on a C5 band -- and their
-    // parity is statistical in any case): chunks of >= 16 samples, at most 16 chunks, at most 4 GiB of chunk sums.
+    // Split a tile's samples over several workgroups (CGRT_GRID_SPLIT_SAMPLES, opt-in for every scene since the cost
+    // scheduler balances Bezier scenes too): chunks of >= 16 samples, at most 16 chunks, at most 4 GiB of chunk sums.
     g.chunks = 1;
     g.chunk_spp = grid->spp;
     g.partial = nullptr;
@@ -706,10 +711,9 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     static const long long env_defer_bytes = [] { const char *e = std::getenv("CGRT_DEFER_BYTES"); return e ? std::atoll(e) : 0ll; }();
     static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
     static const int env_units = [] { const char *e = std::getenv("CGRT_UNITS_PER_ITEM"); return e ? std::atoi(e) : 0; }();
-    // deferred Hitpoint values: up to 12 GiB, at most an eighth of the device's memory (MI355X: 288 GB); allocated once per
-    // scene handle, as large as the biggest launch needed it
-    static const size_t mem_eighth = [] { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? tot / 8 : ((size_t)4 << 30); }();
-    const size_t defer_budget = env_defer_bytes > 0 ? (size_t)env_defer_bytes : std::min((size_t)12 << 30, mem_eighth);
+    // deferred Hitpoint values: up to 12 GiB, at most an eighth of THIS scene's device (MI355X: 288 GB; read at commit -- a
+    // process may drive devices of different sizes); allocated once per scene handle, as large as the biggest launch needed it
+    const size_t defer_budget = env_defer_bytes > 0 ? (size_t)env_defer_bytes : std::min((size_t)12 << 30, s->mem_total / 8);
     const int heavy_div = env_heavy_div > 0 ? env_heavy_div : 32;
     const int units_per_item = env_units > 0 ? ((env_units + 63) / 64) * 64 : 256;
     const int maxhp = glass_possible(s, grid) ? 16 : 1;  // Hitpoints per sample: a mirror chain ends in one, a glass tree of depth 5 in <= 16
@@ -730,14 +734,22 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const size_t chunk_bytes_al = (chunk_bytes + 255) & ~(size_t)255;
     const size_t per_tile = tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst;
     size_t scratch_need = chunk_bytes_al + sched_bytes + defer_bytes;
+    // A size this device has refused before is not asked for again (every attempt is a synchronous hipFree plus failing
+    // hipMallocs): the deferred buffer shrinks -- fewer heavy tiles, same image -- until the need lies below it.
+    while (s->scratch_refused && scratch_need >= s->scratch_refused && kmax > 0) {
+        kmax /= 2;
+        defer_bytes = kmax ? kmax * per_tile + 256 : 0;
+        scratch_need = chunk_bytes_al + sched_bytes + defer_bytes;
+    }
     if (scratch_need > 0 && s->scratch_bytes < scratch_need) {
         if (s->scratch) (void)hipFree(s->scratch);
         s->scratch = nullptr;
         s->scratch_bytes = 0;
-        // a device short of memory gets a smaller deferred buffer (fewer heavy tiles, same image) before it gets an error
+        // a device short of memory gets a smaller deferred buffer before it gets an error
         while (hipMalloc(&s->scratch, scratch_need) != hipSuccess) {
             (void)hipGetLastError();
             s->scratch = nullptr;
+            if (!s->scratch_refused || scratch_need < s->scratch_refused) s->scratch_refused = scratch_need;
             if (kmax == 0) return fail(CGRT_ERR_DEVICE, "cannot allocate launch scratch (chunk sums / schedule / deferred Hitpoint values)");
             kmax /= 2;
             defer_bytes = kmax ? kmax * per_tile + 256 : 0;
@@ -924,6 +936,18 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
 }  // extern "C"
 
 
+// Row e: global row h of the frame = local row (stripe / nshares) * S + h % S of share stripe % nshares (the inverse of
+// global_row()); one workgroup column per 256 floats of a row, blockIdx.y = the row.  Rows of absent shares are zeroed.
+__global__ void unpermute_stripes_kernel(const float *__restrict__ shares, int n_present, int nshares, int row_floats, int S,
+                                         int rows_local, float *__restrict__ frame) {
+    const int h = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= row_floats) return;
+    const int stripe = h / S, share = stripe % nshares, j = (stripe / nshares) * S + h % S;
+    float v = 0.f;
+    if (share < n_present && j < rows_local) v = shares[((size_t)share * rows_local + (size_t)j) * row_floats + x];
+    frame[(size_t)h * row_floats + x] = v;
+}
+
 // Eye pass with Hitpoint capture into a device buffer of `cap` records (10 doubles each); *count = hitpoints produced.
 // *d_rec_out is hipMalloc'ed here (caller frees) unless cap == 0.
 static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, uint64_t cap,
@@ -993,6 +1017,19 @@ int cgrt_trace_grid_hitpoints(const cgrt_scene *s, const cgrt_camera *cam, const
     }
     if (d_rec) (void)hipFree(d_rec);
     return rc;
+}
+
+int cgrt_unpermute_stripes(const float *shares, int n_present, int nshares, int width, int height, int stripe_rows,
+                           int rows_local, int channels, float *frame, void *stream) {
+    if (!shares || !frame || width <= 0 || height <= 0 || channels <= 0 || nshares < 1 || n_present < 1 || n_present > nshares ||
+        stripe_rows <= 0 || rows_local <= 0 || rows_local % stripe_rows)
+        return fail(CGRT_ERR_INVALID, "cgrt_unpermute_stripes: bad argument");
+    const int row_floats = width * channels;
+    const dim3 grid((unsigned)((row_floats + 255) / 256), (unsigned)height);
+    hipLaunchKernelGGL(unpermute_stripes_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), shares, n_present, nshares,
+                       row_floats, stripe_rows, rows_local, frame);
+    HIP_TRY(hipGetLastError());
+    return CGRT_OK;
 }
 
 int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,

@@ -1,7 +1,10 @@
 // The eye pass of the reference's render(objs) across the GPUs of one node from one C++ process
 // (include/cgrt_host_sharded.hpp: a host thread per GPU, block-cyclic stripes, ncclSend/ncclRecv gather to GPU 0).
 //
-//   cgrt_sharded [--gpus N] [--width W] [--height H] [--spp S] [--dof] [--stripe ROWS] [--raw out.f32]
+//   cgrt_sharded [--gpus N] [--width W] [--height H] [--spp S] [--dof] [--stripe ROWS] [--raw out.f32] [--emulate SHARES]
+//
+// --emulate SHARES (one-GPU machines): deal the stripes to SHARES shares, render them one after another on GPU 0 and
+// assemble the frame with the same device un-permute the N > 1 path uses -- everything but the RCCL transfers.
 //
 // Scene: C2 (BASELINE.json configs[1]: the five wall spheres of main.cpp:281-285 + diffuse, mirror and glass spheres).
 // Built by hipcc (HIP runtime + RCCL); run on this project's one-GPU box with N = 1 only -- the N > 1 path (communicator
@@ -21,7 +24,7 @@ int main(int argc, char *argv[]) {
     rp.width = 1920;
     rp.height = 1080;
     rp.num_of_samples = 64;
-    int gpus = 0, stripe = 8;
+    int gpus = 0, stripe = 8, emulate = 0;
     std::string raw;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -31,6 +34,7 @@ int main(int argc, char *argv[]) {
         else if (a == "--height") rp.height = std::atoi(next());
         else if (a == "--spp") rp.num_of_samples = std::atoi(next());
         else if (a == "--stripe") stripe = std::atoi(next());
+        else if (a == "--emulate") emulate = std::atoi(next());
         else if (a == "--dof") rp.depth_of_field = true;
         else if (a == "--raw") raw = next();
     }
@@ -48,7 +52,7 @@ int main(int argc, char *argv[]) {
     std::vector<float> image;
     ShardedStats st;
     try {
-        render_sharded(objs, rp, image, gpus, stripe, &st);
+        render_sharded(objs, rp, image, gpus, stripe, &st, emulate);
     } catch (const Error &e) {
         std::fprintf(stderr, "render_sharded failed (%d): %s\n", e.code, e.what());
         return 1;

@@ -216,6 +216,13 @@ int cgrt_scene_wide_dump(const cgrt_scene *s, int tree, int32_t *nwide, int32_t 
 int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,
                     uint32_t *nhit, uint64_t *counters, void *stream);
 
+/* Row e of SURVEY.md section 8: the un-permute that follows the framebuffer gather.  shares = n_present buffers
+ * [rows_local][width][channels] float, share-major (share r's local row j is global row ((j / stripe_rows) * nshares + r) *
+ * stripe_rows + j % stripe_rows, as in cgrt_grid); frame = [height][width][channels].  Rows of shares >= n_present are
+ * written as zero.  DEVICE pointers on the current device; asynchronous on `stream`. */
+int cgrt_unpermute_stripes(const float *shares, int n_present, int nshares, int width, int height, int stripe_rows,
+                           int rows_local, int channels, float *frame, void *stream);
+
 /* Convenience form with HOST output buffers: allocates device scratch, runs, synchronises and copies back
  * (counters are overwritten, not added to). */
 int cgrt_trace_grid_host(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid *grid, float *rgb,
