@@ -82,6 +82,8 @@ def resolve(args, n):
         if n > 1:
             cfg["workload"] += ("; strong scaling: the same frame split over %d GPUs" % n if scaling == "strong" else
                                 "; weak scaling: same view at %d x the pixels (%dx%d)" % (n, W, H))
+            if scaling != "strong":  # the frame that was rendered, not the N = 1 frame's size
+                cfg["metric"] = "Mrays/sec (primary+secondary) at %dx%d spp=64 (C2's view at %d x the pixels of 1920x1080)" % (W, H, n)
     elif c == "c4":
         cfg = dict(name="c4", W=4096, H=4096, spp=256, stripe_rows=args.stripe_rows or 16, shares=n, scaling="strong",
                    steps=5, warmup=1,
@@ -188,27 +190,43 @@ def other_configs(dev_index):
 
     out = {}
 
-    def eye(name, objs, cam, w, h, spp):
+    flops = load_flops()
+
+    def eye(name, objs, cam, w, h, spp, rows=None, stripe=None, flop_key=None):
         sc = cg.Scene(objs, device=dev_index)
-        buf = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:%d" % dev_index)
+        rows = h if rows is None else rows
+        buf = torch.zeros((rows, w, 3), dtype=torch.float32, device="cuda:%d" % dev_index)
         cnt = torch.zeros(8, dtype=torch.int64, device=buf.device)
+        kw = dict(rows=rows, stripe=stripe, out=buf, nhit=False, counters=cnt)
         # warm-up: the same launch once (a scheduled launch sizes the scene handle's scratch by its sample count on first use)
-        sc.trace_grid(w, h, spp, cam, DEPTH, SEED, out=buf, nhit=False, counters=cnt)
+        sc.trace_grid(w, h, spp, cam, DEPTH, SEED, **kw)
         torch.cuda.synchronize()
         cnt.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        sc.trace_grid(w, h, spp, cam, DEPTH, SEED, out=buf, nhit=False, counters=cnt)
+        sc.trace_grid(w, h, spp, cam, DEPTH, SEED, **kw)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         rays = int(cnt[0].item())
+        alg = 12 * w * rows + sc.stats()["scene_bytes_fp64"]
+        rec = {"ms_per_frame": round(ms, 2), "rays": rays, "mrays_per_s": round(rays / ms / 1e3, 1),
+               "kernel": sc.kernel_variant(w, h, spp, cam, DEPTH, rows=rows, stripe=stripe),
+               "kernel_ms": round(ms, 3), "kernel_ms_note": "HIP events around the whole launch sequence of one frame (probe, plan, "
+               "scheduled kernel + light-tile kernel, ordered sum)",
+               "algorithmic_bytes": int(alg), "hbm_achieved_gbps": round(alg / (ms * 1e-3) / 1e9, 3),
+               "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)}
+        rec.update(flop_fields(flops, flop_key, rays, ms))
         sc.close()
-        out[name] = {"ms_per_frame": round(ms, 2), "rays": rays, "mrays_per_s": round(rays / ms / 1e3, 1)}
+        out[name] = rec
 
-    eye("C3 2048x2048 spp64 glass bunny + ChessBoard floor, thin lens", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 64)
-    eye("C4 4096x4096 spp256 dragon (all rows on one GPU), thin lens", scenes.scene_dragon(), scenes.cam_dof(), 4096, 4096, 256)
+    eye("C3 2048x2048 spp64 glass bunny + ChessBoard floor, thin lens", scenes.scene_c3(True), scenes.cam_dof(), 2048, 2048, 64, flop_key="c3")
+    eye("C4 4096x4096 spp256 dragon (all rows on one GPU), thin lens", scenes.scene_dragon(), scenes.cam_dof(), 4096, 4096, 256, flop_key="c4")
     tex = scenes.stone_texture()
+    # configs[4] at its per-GPU size: share 0 of 8 (16-row block-cyclic stripes) of the 8192 x 8192 frame, all 1024 samples --
+    # the frame `bench.py --config c5` times at N = 1
+    eye("C5 8192x8192 spp1024 Bezier vase + stone.jpg bump floor: one GPU's share (8192x1024 rows, stripes = 0 mod 8), thin lens",
+        scenes.scene_c5(tex), scenes.cam_dof(), 8192, 8192, 1024, rows=1024, stripe=(16, 0, C5_SHARES), flop_key="c5")
     objs = scenes.planes(tex) + [scenes.TriangleMesh.from_triangles(scenes.dragon_tris(), (0.25, 0.25, 0.5), 0.0, 0.0, 1)]
     sc = cg.Scene(objs, device=dev_index)
     sc.ppm_render(64, 48, 1, scenes.cam_pinhole(), 5, SEED, nphotons=1000)
@@ -222,11 +240,38 @@ def other_configs(dev_index):
     return out
 
 
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: fp64 vector FMA peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+VALU_ISSUE_PEAK_GINST = 614.4     # wave-instructions/s when every VALU instruction is a 4-cycle fp64 one: 1024 SIMDs x 2.4 GHz / 4
+
+
+def load_flops():
+    """profiles/r03_flops.json: operation counts of the eye pass by the instrumented CPU oracle (tools/flop_count.py)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_flops.json")))["configs"]
+    except Exception:
+        return {}
+
+
+def flop_fields(flops, key, rays, ms):
+    """Algorithmic fp64 flops of `rays` rays of configuration `key` and the rate they were done at in `ms` milliseconds."""
+    f = flops.get(key) if key else None
+    if not f:
+        return {}
+    total = f["flops_per_ray"] * rays
+    exact = f["spp_counted"] == f["spp_of_configuration"] and "whole frame" in f["subset"] and f["rays"] == rays
+    tf = total / (ms * 1e-3) / 1e12
+    return {"algorithmic_flops": int(f["counts"]["flops"]) if exact else int(total),
+            "algorithmic_flops_source": "profiles/r03_flops.json: instrumented CPU oracle, %s (%s)" % (
+                f["subset"], "the frame's exact count" if exact else "%.2f flops per ray of that subset x this frame's %d rays" % (f["flops_per_ray"], rays)),
+            "flops_per_ray": round(f["flops_per_ray"], 2), "achieved_tflops_fp64": round(tf, 3),
+            "frac_of_fp64_valu_peak": round(tf / FP64_VALU_PEAK_TFLOPS, 4)}
+
+
 def profile_replay(cfg, n):
     """PMC figures of the committed rocprofv3 passes of this same command (not measured in this run)."""
     if cfg["name"] != "c2" or n != 1:
         return None, None
-    for fn in ("r02_pmc.json", "r01_pmc.json"):
+    for fn in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         ppath = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(ppath):
             continue
@@ -482,7 +527,25 @@ def main():
                         (" (+ the chunk-sum finalize kernel: Bezier scenes split a tile's samples)" if cfg["name"] == "c5" else ""),
                 "kernel_mrays_per_s": round(rays_per_step / n / (kern_ms * 1e-3) / 1e6, 2),
                 "lane_utilisation": round(total_rays / max(1, 64 * int(cnt[2].item())), 4),
-                "traffic_from_profile": traffic_prof, "valu_from_profile": valu_prof}
+                "traffic_from_profile": traffic_prof, "valu_from_profile": valu_prof,
+                "stated_bound": "fp64 VALU issue (see roofline_valu): HBM is reported because the north star asks for it"}
+            # the roof that binds: fp64 vector ALU.  flops: counted exactly by the instrumented CPU oracle for this frame
+            # (profiles/r03_flops.json); instructions: SQ_INSTS_VALU of the committed PMC pass of this same command.
+            rv = {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms": round(kern_ms, 4)}
+            ff = flop_fields(load_flops(), cfg["name"], int(rays_per_step / n), kern_ms)
+            if ff:
+                rv.update({"achieved": ff["achieved_tflops_fp64"], "frac": ff["frac_of_fp64_valu_peak"],
+                           "algorithmic_flops": ff["algorithmic_flops"], "flops_per_ray": ff["flops_per_ray"],
+                           "algorithmic_flops_source": ff["algorithmic_flops_source"]})
+            else:
+                rv.update({"achieved": None, "frac": None})
+            if valu_prof:
+                gi = valu_prof["wave_insts_per_launch"] / (kern_ms * 1e-3) / 1e9
+                rv["valu_issue"] = {"wave_insts_per_launch": valu_prof["wave_insts_per_launch"], "achieved_ginst_per_s": round(gi, 1),
+                                    "peak_ginst_per_s": VALU_ISSUE_PEAK_GINST, "frac": round(gi / VALU_ISSUE_PEAK_GINST, 4),
+                                    "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction",
+                                    "source": valu_prof["source"] + "; time = this run's HIP events"}
+            line["roofline_valu"] = rv
             cpu_spp = args.cpu_spp
             if cpu_spp is None or cpu_spp > 0:
                 with stdout_to_stderr():

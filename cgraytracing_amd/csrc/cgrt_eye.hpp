@@ -20,6 +20,14 @@ struct Pending {  // a refracted child waiting for its turn (main.cpp:157)
 #define CGRT_BEZ_WAVES 2
 #endif
 static constexpr int kBezWaves = CGRT_BEZ_WAVES;  // waves per SIMD the Bezier variants are compiled for
+#ifndef CGRT_TREE_WAVES
+#define CGRT_TREE_WAVES 3
+#endif
+#ifndef CGRT_SCHED_TREE_WAVES
+#define CGRT_SCHED_TREE_WAVES CGRT_TREE_WAVES
+#endif
+static constexpr int kTreeWaves = CGRT_TREE_WAVES;             // ... the tree-capable tile kernels
+static constexpr int kSchedTreeWaves = CGRT_SCHED_TREE_WAVES;  // ... the tree-capable scheduled kernels (unit queue + tile queue)
 
 struct HitpointSink {
     double *rec;                // cap x 10 doubles: f(3) pos(3) normal(3) label
@@ -472,7 +480,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
 
 // One launch = tile workgroups only (probe, image order, Hitpoint capture) ...
 template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256>
-__global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? 3 : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+__global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? kTreeWaves : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters,
                                                              HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? 3 : 4)) void trace_g
 // tile workgroups take over the slots as the heavy waves retire -- no seam between two launches.  Each body keeps its own
 // register allocation (the paths are disjoint); the kernel's register and scratch sizes are the larger of the two.
 template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, int NT = 256>
-__global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? 3 : 4)) void trace_grid_sched_kernel(DeviceScene sc, GridParams g,
+__global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? kSchedTreeWaves : 4)) void trace_grid_sched_kernel(DeviceScene sc, GridParams g,
                                                                                          float *__restrict__ rgb,
                                                                                          uint32_t *__restrict__ nhit_out,
                                                                                          unsigned long long *__restrict__ counters) {

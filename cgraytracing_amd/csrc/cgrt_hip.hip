@@ -872,7 +872,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         // heavy: cost x spp > (total cost x spp / wave slots) / heavy_div
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
-        const int wave_slots = n_cu * 4 * (one_wave ? kBezWaves : (trees ? 3 : 4));
+        const int wave_slots = n_cu * 4 * (one_wave ? kBezWaves : (trees ? kSchedTreeWaves : 4));
         // tiles through a queue too (GridParams::border) unless their samples are split over workgroups or the workgroups are
         // single waves (trace_grid_sched_kernel)
         static const bool env_no_tile_queue = [] { const char *e = std::getenv("CGRT_NO_TILE_QUEUE"); return e && *e && *e != '0'; }();

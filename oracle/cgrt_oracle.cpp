@@ -26,26 +26,45 @@
 #include "cgrt_rng.h"
 #include "cgrt_testapi.h"
 
+// `real`: the scalar of the restated algorithm.  The oracle proper (liborc.so) uses double.  The INSTRUMENTED build
+// (liborc_flops.so, -DORC_COUNT_FLOPS; SURVEY.md section 8d "count these exactly") wraps the same double in a struct that
+// counts every arithmetic operation (cgrt_flopcount.h); values, and therefore images, are identical.
+#ifdef ORC_COUNT_FLOPS
+#include "cgrt_flopcount.h"
+namespace orc { thread_local FlopCounters g_fc; }
+#else
+namespace orc {
+typedef double real;
+using std::atan; using std::ceil; using std::cos; using std::exp; using std::fabs; using std::floor; using std::pow; using std::sin; using std::sqrt;
+static inline double plain(double a) { return a; }
+}
+#endif
+namespace orc {
+// the C API's double arrays seen as arrays of `real` (the counting struct holds exactly one double)
+static_assert(sizeof(real) == sizeof(double), "real wraps one double");
+static inline real *as_real(double *p) { return reinterpret_cast<real *>(p); }
+}
+
 namespace orc {
 
 // ---------------------------------------------------------------- vec3.h:11-119
 struct V3 {
-    double x, y, z;
-    V3(double a = 0, double b = 0, double c = 0) : x(a), y(b), z(c) {}
+    real x, y, z;
+    V3(real a = 0, real b = 0, real c = 0) : x(a), y(b), z(c) {}
 };
 static inline V3 operator+(const V3 &a, const V3 &b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline V3 operator-(const V3 &a, const V3 &b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline V3 operator-(const V3 &a) { return V3(-a.x, -a.y, -a.z); }
-static inline V3 operator*(const V3 &a, double f) { return V3(a.x * f, a.y * f, a.z * f); }
+static inline V3 operator*(const V3 &a, real f) { return V3(a.x * f, a.y * f, a.z * f); }
 static inline V3 mul(const V3 &a, const V3 &b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
-static inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline real dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static inline V3 cross(const V3 &a, const V3 &b) {
     return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-static inline double norm(const V3 &a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline real norm(const V3 &a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 // vec3.h:36-44: scales by 1/len only when len > 0
 static inline V3 normalized(V3 a) {
-    double len = norm(a);
+    real len = norm(a);
     if (len > 0) {
         a.x *= 1 / len;
         a.y *= 1 / len;
@@ -54,13 +73,13 @@ static inline V3 normalized(V3 a) {
     return a;
 }
 // vec3.h:95-97 (Sarrus, this exact association)
-static inline double det3(const V3 &a, const V3 &b, const V3 &c) {
+static inline real det3(const V3 &a, const V3 &b, const V3 &c) {
     return (a.x * b.y * c.z + b.x * c.y * a.z + c.x * a.y * b.z - a.x * c.y * b.z - b.x * a.y * c.z -
             c.x * b.y * a.z);
 }
 // vec3.h:103-119
 static inline bool inv3(const V3 &a, const V3 &b, const V3 &c, V3 &ra, V3 &rb, V3 &rc) {
-    double d = det3(a, b, c);
+    real d = det3(a, b, c);
     if (d < 1e-4 && d > -1e-4) return false;
     ra.x = (b.y * c.z - b.z * c.y) / d;
     ra.y = (c.y * a.z - c.z * a.y) / d;
@@ -74,25 +93,25 @@ static inline bool inv3(const V3 &a, const V3 &b, const V3 &c, V3 &ra, V3 &rb, V
     return true;
 }
 // util.h:16-42
-static inline double max3(double a, double b, double c) { return (a > b && a > c) ? a : (b > c ? b : c); }
-static inline double min3(double a, double b, double c) { return (a < b && a < c) ? a : (b < c ? b : c); }
+static inline real max3(real a, real b, real c) { return (a > b && a > c) ? a : (b > c ? b : c); }
+static inline real min3(real a, real b, real c) { return (a < b && a < c) ? a : (b < c ? b : c); }
 
-static const double EPS = 1e-4;      // main.cpp:24
-static const double INF = 1e10;      // main.cpp:25, objects.h:15
-static const double BOXEPS = 1e-4;   // objects.h:144
+static const real EPS = 1e-4;      // main.cpp:24
+static const real INF = 1e10;      // main.cpp:25, objects.h:15
+static const real BOXEPS = 1e-4;   // objects.h:144
 static const int MINKD = 10;         // objects.h:143
 
 // ---------------------------------------------------------------- keyed stream
 struct Rng {
     uint64_t key;
     uint32_t ctr;
-    double u01() { return (double)cgrt_rand31(key, ctr++) / 2147483647.0; }  // sampling.h:31-33
+    real u01() { return (real)cgrt_rand31(key, ctr++) / 2147483647.0; }  // sampling.h:31-33
 };
 // sampling.h:35-43
-static V3 lens_sample(Rng &r, double radius) {
+static V3 lens_sample(Rng &r, real radius) {
     while (true) {
-        double x = r.u01() * 2.0 - 1;
-        double y = r.u01() * 2.0 - 1;
+        real x = r.u01() * 2.0 - 1;
+        real y = r.u01() * 2.0 - 1;
         if (x * x + y * y < 1) return V3(x, y, 0) * radius;
     }
 }
@@ -102,9 +121,9 @@ struct Tri {
     V3 pa, pb, pc;
 };
 // objects.h:96-111
-static inline bool tri_intersect(const Tri &t, const V3 &o, const V3 &d, double &len, V3 &n) {
+static inline bool tri_intersect(const Tri &t, const V3 &o, const V3 &d, real &len, V3 &n) {
     V3 e1 = t.pa - t.pb, e2 = t.pa - t.pc, s = t.pa - o;
-    double det1 = det3(d, e1, e2), det2 = det3(s, e1, e2), det3_ = det3(d, s, e2), det4 = det3(d, e1, s);
+    real det1 = det3(d, e1, e2), det2 = det3(s, e1, e2), det3_ = det3(d, s, e2), det4 = det3(d, e1, s);
     if (det2 / det1 > 0.0 && det3_ / det1 >= 0.0 && det4 / det1 >= 0.0 && (det3_ + det4) / det1 <= 1.0) {
         len = det2 / det1;
         n = normalized(cross(t.pa - t.pb, t.pa - t.pc));
@@ -115,7 +134,7 @@ static inline bool tri_intersect(const Tri &t, const V3 &o, const V3 &d, double 
 
 // ---------------------------------------------------------------- objects.h:147-332
 struct Node {
-    double xmax, xmin, ymax, ymin, zmax, zmin;
+    real xmax, xmin, ymax, ymin, zmax, zmin;
     int left, right;
     std::vector<int> ids;  // triangleList (ids into Tree::tris)
 };
@@ -136,9 +155,9 @@ struct Tree {
             nd.xmin = nd.ymin = nd.zmin = INF;
             for (size_t i = 0; i < sub.size(); i++) {
                 const Tri &a = tris[sub[i]];
-                double mxx = max3(a.pa.x, a.pb.x, a.pc.x), mxy = max3(a.pa.y, a.pb.y, a.pc.y),
+                real mxx = max3(a.pa.x, a.pb.x, a.pc.x), mxy = max3(a.pa.y, a.pb.y, a.pc.y),
                        mxz = max3(a.pa.z, a.pb.z, a.pc.z);
-                double mnx = min3(a.pa.x, a.pb.x, a.pc.x), mny = min3(a.pa.y, a.pb.y, a.pc.y),
+                real mnx = min3(a.pa.x, a.pb.x, a.pc.x), mny = min3(a.pa.y, a.pb.y, a.pc.y),
                        mnz = min3(a.pa.z, a.pb.z, a.pc.z);
                 if (nd.xmax < mxx) nd.xmax = mxx;
                 if (nd.ymax < mxy) nd.ymax = mxy;
@@ -177,7 +196,7 @@ struct Tree {
 
     // objects.h:166-200: six face tests, in this order
     static bool box_hit(const Node &b, const V3 &o, const V3 &d) {
-        double t;
+        real t;
         V3 p;
         t = (b.xmax - o.x) / d.x; p = o + d * t;
         if (t > 0 && p.y >= b.ymin - BOXEPS && p.y <= b.ymax + BOXEPS && p.z >= b.zmin - BOXEPS && p.z <= b.zmax + BOXEPS) return true;
@@ -195,12 +214,12 @@ struct Tree {
     }
     // objects.h:269-316.  Returns the number of times the running minimum improved (Q5), visits both
     // children unconditionally (Q6).
-    int subtree(const V3 &o, const V3 &d, double &len, V3 &n, int cur, uint64_t *stats) const {
+    int subtree(const V3 &o, const V3 &d, real &len, V3 &n, int cur, uint64_t *stats) const {
         const Node &nd = nodes[cur];
         if (stats) stats[0]++;
         if (!box_hit(nd, o, d)) return 0;
         if ((int)nd.ids.size() < MINKD) {
-            double lt;
+            real lt;
             V3 nt;
             int counter = 0;
             len = INF;
@@ -216,7 +235,7 @@ struct Tree {
             }
             return counter;
         }
-        double ll, lr;
+        real ll, lr;
         V3 nl, nr;
         int cl = subtree(o, d, ll, nl, nd.left, stats);
         int cr = subtree(o, d, lr, nr, nd.right, stats);
@@ -228,7 +247,7 @@ struct Tree {
         return cl + cr;
     }
     // objects.h:318-332
-    bool intersect(const V3 &o, const V3 &d, double &len, V3 &n, uint64_t *stats) const {
+    bool intersect(const V3 &o, const V3 &d, real &len, V3 &n, uint64_t *stats) const {
         int counter = subtree(o, d, len, n, 0, stats);
         if (counter > 0) {
             if (counter % 2 == 0) n = n * ((dot(n, d) < 0) ? 1 : -1);
@@ -244,15 +263,15 @@ struct Texture {
     int rows = 0, cols = 0;
     std::vector<uint8_t> rgb;  // texel = byte/256 (main.cpp:303-316)
     V3 normal, position;
-    double lenx = 0, leny = 0;
+    real lenx = 0, leny = 0;
     bool isbump = false;
-    std::vector<double> height;  // texture.h:26-37
+    std::vector<real> height;  // texture.h:26-37
     V3 texel(int r, int c) const {
         // the reference would index out of bounds here; clamp
         r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
         c = c < 0 ? 0 : (c >= cols ? cols - 1 : c);
         const uint8_t *p = &rgb[3 * ((size_t)r * cols + c)];
-        return V3((double)p[0] / 256.0, (double)p[1] / 256.0, (double)p[2] / 256.0);
+        return V3((real)p[0] / 256.0, (real)p[1] / 256.0, (real)p[2] / 256.0);
     }
     void make_height() {
         height.assign((size_t)rows * cols, 0.0);
@@ -260,8 +279,8 @@ struct Texture {
         for (int i = 0; i < rows; i++)
             for (int j = 0; j < cols; j++) {
                 V3 d = texel(i, j);
-                double h = (0.299 * d.x + 0.587 * d.y + 0.114 * d.z);
-                h = 1 - std::exp(-3.3 * h);
+                real h = (0.299 * d.x + 0.587 * d.y + 0.114 * d.z);
+                h = 1 - exp(-3.3 * h);
                 h *= 0.5;
                 height[(size_t)i * cols + j] = h;
             }
@@ -270,27 +289,27 @@ struct Texture {
     bool color(const V3 &point, V3 &out) const {
         V3 d = point - position;
         d = d - normal * dot(d, normal);
-        const double te = 1e-2;
+        const real te = 1e-2;
         if (d.x < te && d.x > -te) {
             if (0 < d.y && d.y < lenx && 0 < d.z && d.z < leny) {
-                int id1 = (int)std::floor(d.y / lenx * rows);
-                int id2 = (int)std::floor(d.z / leny * cols);
+                int id1 = (int)floor(d.y / lenx * rows);
+                int id2 = (int)floor(d.z / leny * cols);
                 out = texel(id1, id2);
                 return true;
             }
             return false;
         } else if (d.y < te && d.y > -te) {
             if (0 < d.x && d.x < lenx && 0 < d.z && d.z < leny) {
-                int id1 = (int)std::floor(d.x / lenx * cols);
-                int id2 = (int)std::floor(d.z / leny * rows);
+                int id1 = (int)floor(d.x / lenx * cols);
+                int id2 = (int)floor(d.z / leny * rows);
                 out = texel(id2, id1);
                 return true;
             }
             return false;
         } else if (d.z < te && d.z > -te) {
             if (0 < d.x && d.x < lenx && 0 < d.y && d.y < leny) {
-                int id1 = (int)std::floor(d.x / lenx * cols);
-                int id2 = (int)std::floor(d.y / leny * rows);
+                int id1 = (int)floor(d.x / lenx * cols);
+                int id2 = (int)floor(d.y / leny * rows);
                 out = texel(rows - 1 - id2, id1);
                 return true;
             }
@@ -305,10 +324,10 @@ enum Kind { SPHERE, PLANE, MESH, BEZIER };
 struct Obj {
     Kind kind;
     V3 color;
-    double refl = 0, transp = 0;
+    real refl = 0, transp = 0;
     // sphere (objects.h:83-88)
     V3 center;
-    double radius = 0, radius2 = 0;
+    real radius = 0, radius2 = 0;
     // plane (objects.h:541-547)
     V3 position, normal;
     int tex = -1;
@@ -319,7 +338,7 @@ struct Obj {
     int objtype = 0;
     // bezier (bezier.h:303-313)
     std::vector<V3> cp;
-    double xmax = 0, xmin = 0, ymax = 0, ymin = 0, zmax = 0, zmin = 0;
+    real xmax = 0, xmin = 0, ymax = 0, ymin = 0, zmax = 0, zmin = 0;
 };
 
 struct Scene {
@@ -333,31 +352,31 @@ struct Scene {
 };
 
 // objects.h:45-68
-static bool sphere_intersect(const Obj &s, const V3 &o, const V3 &d, double &len, V3 &n) {
+static bool sphere_intersect(const Obj &s, const V3 &o, const V3 &d, real &len, V3 &n) {
     V3 l = s.center - o;
-    double tca = dot(l, d);
-    double l2 = dot(l, l);
+    real tca = dot(l, d);
+    real l2 = dot(l, l);
     if (tca < 0 && l2 > s.radius2) return false;
-    double d2 = dot(l, l) - tca * tca;
+    real d2 = dot(l, l) - tca * tca;
     if (d2 > s.radius2) return false;
-    double thc = std::sqrt(s.radius2 - d2);
-    double t0 = tca - thc, t1 = tca + thc;
+    real thc = sqrt(s.radius2 - d2);
+    real t0 = tca - thc, t1 = tca + thc;
     len = (t0 < 0) ? t1 : t0;
     V3 p = o + d * len;
     n = normalized(p - s.center);
     return true;
 }
 // objects.h:505-524
-static bool plane_intersect(const Scene &sc, const Obj &pl, const V3 &o, const V3 &d, double &len, V3 &n,
+static bool plane_intersect(const Scene &sc, const Obj &pl, const V3 &o, const V3 &d, real &len, V3 &n,
                             uint64_t *stats) {
     V3 dd = pl.position - o;
     len = dot(dd, pl.normal) / dot(d, pl.normal);
     if (len > 0) {
         n = pl.normal;
-        double lenp;
+        real lenp;
         V3 np;
         bool isbump = pl.tex >= 0 && sc.textures[pl.tex]->isbump;  // Q4: default Texture => false
-        if (isbump && std::fabs(pl.normal.y - 1) < 1e-5 && pl.has_bump_tree && pl.bump.intersect(o, d, lenp, np, stats)) {
+        if (isbump && fabs(pl.normal.y - 1) < 1e-5 && pl.has_bump_tree && pl.bump.intersect(o, d, lenp, np, stats)) {
             if (lenp < len && lenp > 0) {
                 len = lenp;
                 n = np;
@@ -368,29 +387,29 @@ static bool plane_intersect(const Scene &sc, const Obj &pl, const V3 &o, const V
     return false;
 }
 // objects.h:405-455
-static bool mesh_intersect(const Obj &m, const V3 &o, const V3 &d, double &len, V3 &n, uint64_t *stats) {
+static bool mesh_intersect(const Obj &m, const V3 &o, const V3 &d, real &len, V3 &n, uint64_t *stats) {
     bool res = m.tree.intersect(o, d, len, n, stats);
     if (m.objtype == 2) n = n * ((dot(n, V3(0, 1, 0)) > 0) ? 1 : -1);
     return res;
 }
 
 // ---------------------------------------------------------------- bezier.h
-static const double Cni[7][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0},
+static const real Cni[7][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0},
                                  {1, 3, 3, 1, 0, 0, 0}, {1, 4, 6, 4, 1, 0, 0}, {1, 5, 10, 10, 5, 1, 0},
                                  {1, 6, 15, 20, 15, 6, 1}};
 // bezier.h:30-40
-static double Bern(int n, int i, double t) {
+static real Bern(int n, int i, real t) {
     if (i > n || i < 0) return 0;
-    return Cni[n][i] * std::pow(1 - t, (double)(n - i)) * std::pow(t, (double)i);
+    return Cni[n][i] * pow(1 - t, (real)(n - i)) * pow(t, (real)i);
 }
-static double dBern(int n, int i, double t) { return Bern(n - 1, i - 1, t) * (double)i - Bern(n - 1, i, t) * (double)(n - i); }
-static V3 bez_valueP(const Obj &b, double u) {  // bezier.h:127-134
+static real dBern(int n, int i, real t) { return Bern(n - 1, i - 1, t) * (real)i - Bern(n - 1, i, t) * (real)(n - i); }
+static V3 bez_valueP(const Obj &b, real u) {  // bezier.h:127-134
     V3 res;
     int n = (int)b.cp.size();
     for (int i = 0; i < n; i++) res = res + b.cp[i] * Bern(n - 1, i, u);
     return res;
 }
-static V3 bez_gradP(const Obj &b, double u) {  // bezier.h:135-142
+static V3 bez_gradP(const Obj &b, real u) {  // bezier.h:135-142
     V3 res;
     int n = (int)b.cp.size();
     for (int i = 0; i < n; i++) res = res + b.cp[i] * dBern(n - 1, i, u);
@@ -398,19 +417,19 @@ static V3 bez_gradP(const Obj &b, double u) {  // bezier.h:135-142
 }
 static V3 bez_func(const Obj &b, const V3 &p, const V3 &o, const V3 &d) {  // bezier.h:144-149
     V3 t = bez_valueP(b, p.y);
-    t.x = t.z * std::sin(p.z);
-    t.z *= std::cos(p.z);
+    t.x = t.z * sin(p.z);
+    t.z *= cos(p.z);
     return o + d * p.x - b.position - t;
 }
 static void bez_grad(const Obj &b, const V3 &p, const V3 &d, V3 &ra, V3 &rb, V3 &rc) {  // bezier.h:150-162
     ra = d;
     V3 t1 = bez_gradP(b, p.y), t2 = bez_valueP(b, p.y);
-    rb.x = -std::sin(p.z) * t1.z;
+    rb.x = -sin(p.z) * t1.z;
     rb.y = -t1.y;
-    rb.z = -std::cos(p.z) * t1.z;
-    rc.x = -std::cos(p.z) * t2.z;
+    rb.z = -cos(p.z) * t1.z;
+    rc.x = -cos(p.z) * t2.z;
     rc.y = 0;
-    rc.z = std::sin(p.z) * t2.z;
+    rc.z = sin(p.z) * t2.z;
 }
 static uint64_t g_jitter_events = 0;  // test observability only
 // bezier.h:163-214
@@ -427,7 +446,7 @@ static V3 bez_newton(const Obj &b, const V3 &initial, const V3 &o, const V3 &dir
             g_jitter_events++;
             // bezier.h:183: Vec3(u(),u(),u()) -- g++ evaluates the arguments right to left (pinned by
             // tests/test_oracle_vs_ref.py::test_bezier_singular_jitter)
-            double uz = rng.u01(), uy = rng.u01(), ux = rng.u01();
+            real uz = rng.u01(), uy = rng.u01(), ux = rng.u01();
             V3 j = V3(ux, uy, uz) * 0.2;
             res = V3(res.x + j.x - 0.1, res.y + j.y - 0.1, res.z + j.z - 0.1);
         }
@@ -439,7 +458,7 @@ static V3 bez_newton(const Obj &b, const V3 &initial, const V3 &o, const V3 &dir
 }
 // bezier.h:72-126 (nearest-face t unused; a face only counts when t < 1e10)
 static bool bez_box(const Obj &b, const V3 &o, const V3 &d) {
-    double len = INF, t;
+    real len = INF, t;
     bool flag = false;
     V3 p;
     t = (b.xmax - o.x) / d.x; p = o + d * t;
@@ -458,32 +477,32 @@ static bool bez_box(const Obj &b, const V3 &o, const V3 &d) {
 }
 // bezier.h:225-290.  `n` is the caller's running normal (stale value is re-oriented when nothing hits,
 // harmless because the return value is then false).
-static bool bezier_intersect(const Obj &b, const V3 &o, const V3 &d, double &len, V3 &n, Rng &rng) {
+static bool bezier_intersect(const Obj &b, const V3 &o, const V3 &d, real &len, V3 &n, Rng &rng) {
     if (!bez_box(b, o, d)) return false;
     bool flag = false;
     len = INF;
     for (int i = 0; i < 10; i++) {
-        double u0 = rng.u01();
-        double t0 = 20 + 10 * rng.u01();
+        real u0 = rng.u01();
+        real t0 = 20 + 10 * rng.u01();
         V3 p = o + d * t0;
         p = p - b.position;
-        double theta = (p.z < 0) ? 3.14159265 + std::atan(p.x / p.z) : std::atan(p.x / p.z);
+        real theta = (p.z < 0) ? 3.14159265 + atan(p.x / p.z) : atan(p.x / p.z);
         V3 res = bez_newton(b, V3(t0, u0, theta), o, d, rng);
         if (norm(bez_func(b, res, o, d)) < 1e-4 && res.x > 0 && res.y <= 1 && res.y >= 0) {
             if (res.x < len) {
                 len = res.x;
                 V3 rp = normalized(bez_gradP(b, res.y));  // bezier.h:215-224
-                n = V3(rp.y * std::sin(res.z), -rp.z, rp.y * std::cos(res.z));
+                n = V3(rp.y * sin(res.z), -rp.z, rp.y * cos(res.z));
                 flag = true;
             }
         }
     }
     n = n * ((dot(n, d) < 0) ? 1 : -1);
-    double newt = b.ymax - o.y;
+    real newt = b.ymax - o.y;
     if (newt > 0.1) {
         newt = newt / d.y;
         V3 np = o + d * newt;
-        double cz = b.cp[b.cp.size() - 1].z;
+        real cz = b.cp[b.cp.size() - 1].z;
         if ((np.x - b.position.x) * (np.x - b.position.x) + (np.z - b.position.z) * (np.z - b.position.z) <= cz * cz) {
             len = newt;
             n = V3(0, 1, 0);
@@ -494,10 +513,10 @@ static bool bezier_intersect(const Obj &b, const V3 &o, const V3 &d, double &len
 
 // ---------------------------------------------------------------- trace(), main.cpp:42-100,129-157
 struct Sink {
-    double *acc = nullptr;      // 3 doubles of the current pixel
+    real *acc = nullptr;      // 3 doubles of the current pixel
     uint32_t *nhit = nullptr;   // of the current pixel
     uint64_t nrays = 0;
-    double *hp = nullptr;
+    real *hp = nullptr;
     int64_t *hp_pix = nullptr;
     uint64_t hp_cap = 0, hp_n = 0;
     int64_t label = 0;
@@ -509,7 +528,7 @@ struct RayCtx {
 
 // `seq`: when non-null (photon pass) Bezier draws continue on that sequential stream, as the reference's rand()
 // does; otherwise (eye pass) they come from the ray's own path-keyed stream.
-static bool obj_intersect(const Scene &sc, int i, const V3 &o, const V3 &d, double &len, V3 &n, const RayCtx &rc,
+static bool obj_intersect(const Scene &sc, int i, const V3 &o, const V3 &d, real &len, V3 &n, const RayCtx &rc,
                           uint32_t path, Sink &sink, Rng *seq = nullptr) {
     const Obj &ob = *sc.objs[i];
     switch (ob.kind) {
@@ -529,10 +548,10 @@ static void trace(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int dep
                   const RayCtx &rc, Sink &sink) {
     if (depth_left <= 0) return;  // main.cpp:46
     sink.nrays++;
-    double len = 0;
+    real len = 0;
     int id = -1;
     V3 normalvec, temp;
-    double nearest = INF;
+    real nearest = INF;
     for (int i = 0; i < (int)sc.objs.size(); i++) {  // main.cpp:55-63 (strict <: first object wins ties, Q1)
         if (obj_intersect(sc, i, org, dir, len, temp, rc, path, sink)) {
             if (len < nearest) {
@@ -561,7 +580,7 @@ static void trace(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int dep
         sink.acc[0] += hf.x; sink.acc[1] += hf.y; sink.acc[2] += hf.z;
         (*sink.nhit)++;
         if (sink.hp && sink.hp_n < sink.hp_cap) {
-            double *o = sink.hp + 9 * sink.hp_n;
+            real *o = sink.hp + 9 * sink.hp_n;
             o[0] = hf.x; o[1] = hf.y; o[2] = hf.z;
             o[3] = P.x; o[4] = P.y; o[5] = P.z;
             o[6] = normalvec.x; o[7] = normalvec.y; o[8] = normalvec.z;
@@ -570,19 +589,19 @@ static void trace(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int dep
         sink.hp_n++;
     } else if (obj.transp < EPS) {  // mirror, main.cpp:129-134
         V3 newdir = dir - normalvec * 2.0 * dot(normalvec, dir);
-        double refl = obj.refl;
+        real refl = obj.refl;
         V3 P2 = P + normalvec * EPS;
         trace(sc, P2, newdir, mul(f, adj) * refl, depth_left - 1, path * 2, rc, sink);
     } else {  // glass, main.cpp:135-157
-        double nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
+        real nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
         V3 refl_dir = dir - n_old * 2.0 * dot(n_old, dir);
         if ((cos2t = 1 - nnt * nnt * (1 - ddn * ddn)) < 0) {  // TIR keeps adj (Q3)
             trace(sc, P + normalvec * EPS, refl_dir, adj, depth_left - 1, path * 2, rc, sink);
             return;
         }
-        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + std::sqrt(cos2t))));
-        double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
-        double Re = R0 + (1 - R0) * c * c * c * c * c;
+        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
+        real a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
+        real Re = R0 + (1 - R0) * c * c * c * c * c;
         V3 fa = mul(f, adj);
         trace(sc, P + normalvec * EPS, refl_dir, fa * Re, depth_left - 1, path * 2, rc, sink);
         trace(sc, P - normalvec * EPS, refr_dir, fa * (1 - Re), depth_left - 1, path * 2 + 1, rc, sink);
@@ -595,25 +614,25 @@ static void trace(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int dep
 // neighbouring cell whose hash equals its bucket -- normally once, twice on a hash collision inside the 3x3x3 block.
 struct Hitpt {
     V3 f, pos, normal, flux;
-    double r2;
+    real r2;
     int n, h, w;
 };
 struct HashGrid {
     int hashsize, ncell;
-    double celllength;
+    real celllength;
     std::vector<std::vector<Hitpt> > buckets;
-    HashGrid(int hs, double cl) : hashsize(hs) {  // hash.h:22-30
-        ncell = (int)std::ceil(70.0 / cl);
+    HashGrid(int hs, real cl) : hashsize(hs) {  // hash.h:22-30
+        ncell = (int)ceil(70.0 / cl);
         celllength = 70.0 / ncell;
         buckets.assign((size_t)hs, std::vector<Hitpt>());
     }
     unsigned hash(int ix, int iy, int iz) const {  // hash.h:35-37 (wrapping int products)
         return (((unsigned)ix * 73856093u) ^ ((unsigned)iy * 19349663u) ^ ((unsigned)iz * 83492791u)) % (unsigned)hashsize;
     }
-    void coord(double x, double y, double z, int &ix, int &iy, int &iz) const {  // hash.h:38-42
-        ix = (int)std::floor((x - (-35.0)) / celllength);
-        iy = (int)std::floor((y - (-35.0)) / celllength);
-        iz = (int)std::floor((z - (-15.0)) / celllength);
+    void coord(real x, real y, real z, int &ix, int &iy, int &iz) const {  // hash.h:38-42
+        ix = (int)floor((x - (-35.0)) / celllength);
+        iy = (int)floor((y - (-35.0)) / celllength);
+        iz = (int)floor((z - (-15.0)) / celllength);
     }
     void insert(const Hitpt &hp) {  // hash.h:43-54
         int ix, iy, iz;
@@ -621,12 +640,12 @@ struct HashGrid {
         buckets[hash(ix, iy, iz)].push_back(hp);
     }
 };
-static const double PI_REF = 3.14159265358979;  // main.cpp:26
+static const real PI_REF = 3.14159265358979;  // main.cpp:26
 
 // sampling.h:11-29 on the photon's sequential stream
 static V3 sample_sphere(Rng &r) {
     while (true) {
-        double x = r.u01() * 2.0 - 1, y = r.u01() * 2.0 - 1, z = r.u01() * 2.0 - 1;
+        real x = r.u01() * 2.0 - 1, y = r.u01() * 2.0 - 1, z = r.u01() * 2.0 - 1;
         if (x * x + y * y + z * z <= 1) return normalized(V3(x, y, z));
     }
 }
@@ -639,12 +658,12 @@ static V3 sample_halfsphere(Rng &r, const V3 &dir) {
 
 // eye-pass trace that stores Hitpoints (main.cpp:85-100) instead of accumulating them
 static void trace_store(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, int depth_left, uint32_t path,
-                        const RayCtx &rc, HashGrid &ht, int lw, int lh, double r0, Sink &sink) {
+                        const RayCtx &rc, HashGrid &ht, int lw, int lh, real r0, Sink &sink) {
     if (depth_left <= 0) return;
-    double len = 0;
+    real len = 0;
     int id = -1;
     V3 normalvec, temp;
-    double nearest = INF;
+    real nearest = INF;
     for (int i = 0; i < (int)sc.objs.size(); i++)
         if (obj_intersect(sc, i, org, dir, len, temp, rc, path, sink) && len < nearest) { id = i; nearest = len; normalvec = temp; }
     if (id == -1) return;
@@ -663,15 +682,15 @@ static void trace_store(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, i
         V3 newdir = dir - normalvec * 2.0 * dot(normalvec, dir);
         trace_store(sc, P + normalvec * EPS, newdir, mul(f, adj) * obj.refl, depth_left - 1, path * 2, rc, ht, lw, lh, r0, sink);
     } else {
-        double nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
+        real nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
         V3 refl_dir = dir - n_old * 2.0 * dot(n_old, dir);
         if ((cos2t = 1 - nnt * nnt * (1 - ddn * ddn)) < 0) {
             trace_store(sc, P + normalvec * EPS, refl_dir, adj, depth_left - 1, path * 2, rc, ht, lw, lh, r0, sink);
             return;
         }
-        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + std::sqrt(cos2t))));
-        double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
-        double Re = R0 + (1 - R0) * c * c * c * c * c;
+        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
+        real a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
+        real Re = R0 + (1 - R0) * c * c * c * c * c;
         V3 fa = mul(f, adj);
         trace_store(sc, P + normalvec * EPS, refl_dir, fa * Re, depth_left - 1, path * 2, rc, ht, lw, lh, r0, sink);
         trace_store(sc, P - normalvec * EPS, refr_dir, fa * (1 - Re), depth_left - 1, path * 2 + 1, rc, ht, lw, lh, r0, sink);
@@ -680,20 +699,20 @@ static void trace_store(const Scene &sc, const V3 &org, const V3 &dir, V3 adj, i
 
 // trace(flag=false), main.cpp:42-81,101-128,129-165
 struct EventLog {  // optional record of the diffuse photon hits, in serial order (function-level parity probe)
-    double *out = nullptr;  // 10 doubles each: photon index, P(3), n(3), flux(3)
+    real *out = nullptr;  // 10 doubles each: photon index, P(3), n(3), flux(3)
     uint64_t cap = 0, n = 0;
     int64_t photon = 0;
 };
 static EventLog *g_evlog = nullptr;
 
 static void trace_photon(const Scene &sc, const V3 &org, const V3 &dir, V3 flux, V3 adj, int depth_left, Rng &rng,
-                         HashGrid &ht, double alpha, Sink &sink) {
+                         HashGrid &ht, real alpha, Sink &sink) {
     if (depth_left <= 0) return;
     static const RayCtx none{0, 0, 0};
-    double len = 0;
+    real len = 0;
     int id = -1;
     V3 normalvec, temp;
-    double nearest = INF;
+    real nearest = INF;
     for (int i = 0; i < (int)sc.objs.size(); i++)
         if (obj_intersect(sc, i, org, dir, len, temp, none, 0, sink, &rng) && len < nearest) { id = i; nearest = len; normalvec = temp; }
     if (id == -1) return;
@@ -704,12 +723,12 @@ static void trace_photon(const Scene &sc, const V3 &org, const V3 &dir, V3 flux,
     if (dot(normalvec, dir) > 0) { normalvec = -normalvec; into = false; }
     V3 f = obj.color;
     if (obj.kind == PLANE && obj.tex >= 0) { V3 c; if (sc.textures[obj.tex]->color(P, c)) f = c; }
-    double p = max3(f.x, f.y, f.z);  // main.cpp:79
+    real p = max3(f.x, f.y, f.z);  // main.cpp:79
     if (obj.refl < EPS && obj.transp < EPS) {
         if (g_evlog) {
             if (g_evlog->n < g_evlog->cap) {
-                double *e = g_evlog->out + 10 * g_evlog->n;
-                e[0] = (double)g_evlog->photon;
+                real *e = g_evlog->out + 10 * g_evlog->n;
+                e[0] = (real)g_evlog->photon;
                 e[1] = P.x; e[2] = P.y; e[3] = P.z; e[4] = normalvec.x; e[5] = normalvec.y; e[6] = normalvec.z;
                 e[7] = flux.x; e[8] = flux.y; e[9] = flux.z;
             }
@@ -726,7 +745,7 @@ static void trace_photon(const Scene &sc, const V3 &org, const V3 &dir, V3 flux,
                         Hitpt &hp = bk[i];
                         V3 dd = hp.pos - P;
                         if ((dot(hp.normal, normalvec) > EPS) && (dot(dd, dd) <= hp.r2)) {  // main.cpp:116
-                            double g = (hp.n * alpha + alpha) / (hp.n * alpha + 1.0);    // main.cpp:119
+                            real g = (hp.n * alpha + alpha) / (hp.n * alpha + 1.0);    // main.cpp:119
                             hp.r2 *= g;
                             hp.n++;
                             hp.flux = (hp.flux + mul(hp.f, flux) * (1.0 / PI_REF)) * g;  // main.cpp:122
@@ -740,15 +759,15 @@ static void trace_photon(const Scene &sc, const V3 &org, const V3 &dir, V3 flux,
         trace_photon(sc, P + normalvec * EPS, newdir, mul(f, flux) * obj.refl, mul(f, adj) * obj.refl, depth_left - 1, rng, ht,
                      alpha, sink);
     } else {
-        double nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
+        real nc = 1.0, nt = 1.33, nnt = into ? nc / nt : nt / nc, ddn = dot(dir, normalvec), cos2t;
         V3 refl_dir = dir - n_old * 2.0 * dot(n_old, dir);
         if ((cos2t = 1 - nnt * nnt * (1 - ddn * ddn)) < 0) {
             trace_photon(sc, P + normalvec * EPS, refl_dir, flux, adj, depth_left - 1, rng, ht, alpha, sink);
             return;
         }
-        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + std::sqrt(cos2t))));
-        double a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
-        double Re = R0 + (1 - R0) * c * c * c * c * c;
+        V3 refr_dir = normalized(dir * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
+        real a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : dot(refr_dir, n_old));
+        real Re = R0 + (1 - R0) * c * c * c * c * c;
         V3 fa = mul(f, adj);
         if (rng.u01() < 0.5)  // main.cpp:160-164: Russian roulette; the photon's flux is not attenuated by glass
             trace_photon(sc, P + normalvec * EPS, refl_dir, flux, fa * Re * 0.3, depth_left - 1, rng, ht, alpha, sink);
@@ -776,7 +795,7 @@ struct Tok {
         if (i < t.size() && t[i] == s) { i++; return true; }
         return false;
     }
-    bool num(double &v) {
+    bool num(real &v) {
         if (i >= t.size()) return false;
         char *e;
         v = std::strtod(t[i].c_str(), &e);
@@ -794,13 +813,13 @@ struct Tok {
         return true;
     }
 };
-static bool load_mesh(const char *file, double a, const V3 &b, int type, std::vector<Tri> &out) {
+static bool load_mesh(const char *file, real a, const V3 &b, int type, std::vector<Tri> &out) {
     Tok tk;
     if (!tk.load(file)) return true;  // missing file => freopen fails => empty mesh
-    auto xf = [&](double x, double y, double z) { return V3(x, y, -z) * a + b; };  // objects.h:348,365,384
+    auto xf = [&](real x, real y, real z) { return V3(x, y, -z) * a + b; };  // objects.h:348,365,384
     if (type == 0) {
         while (tk.more()) {
-            double v[9];
+            real v[9];
             if (!tk.lit("begin")) return false;
             for (int k = 0; k < 3; k++) {
                 if (!tk.lit("vertex")) return false;
@@ -815,13 +834,13 @@ static bool load_mesh(const char *file, double a, const V3 &b, int type, std::ve
     if (!tk.integer(num)) return false;
     std::vector<V3> verts;
     for (int i = 0; i < num; i++) {
-        double x, y, z;
+        real x, y, z;
         if (!tk.lit("v") || !tk.num(x) || !tk.num(y) || !tk.num(z)) return false;
         verts.push_back(V3(x, y, -z));
     }
     if (type == 2) {  // optional vn / vt blocks (objects.h:387-392)
-        while (tk.lit("vn")) { double q; tk.num(q); tk.num(q); tk.num(q); }
-        while (tk.lit("vt")) { double q; tk.num(q); tk.num(q); }
+        while (tk.lit("vn")) { real q; tk.num(q); tk.num(q); tk.num(q); }
+        while (tk.lit("vt")) { real q; tk.num(q); tk.num(q); }
     }
     if (!tk.integer(num)) return false;
     for (int i = 0; i < num; i++) {
@@ -992,7 +1011,7 @@ void orc_intersect_batch(void *sp, int obj, const double *org, const double *dir
     Scene *s = (Scene *)sp;
     for (int i = 0; i < n; i++) {
         const Obj &ob = *s->objs[obj];
-        double l = 0;
+        real l = 0;
         V3 nv;
         bool h = false;
         V3 o = v3(org + 3 * i), d = v3(dir + 3 * i);
@@ -1038,15 +1057,15 @@ double orc_trace_grid(void *sp, const orc_camera *cam, const orc_grid *g, int ha
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : total_rays, total_hp)
     for (int h = g->row0; h < g->row0 + g->nrows; h++) {
         Sink sink;
-        sink.hp = hp; sink.hp_pix = hp_pix; sink.hp_cap = hp_cap;
+        sink.hp = as_real(hp); sink.hp_pix = hp_pix; sink.hp_cap = hp_cap;
         if (hp) sink.hp_n = total_hp;  // single-threaded in this mode
         for (int w = 0; w < W; w++) {
             size_t pix = (size_t)(h - g->row0) * W + w;
-            double x = (2.0 * ((double)w / W) - 1) * cam->half_width;               // main.cpp:188
-            double y = (2.0 * ((double)h / H) - 1) * cam->half_width * H / W;       // main.cpp:189
+            real x = (2.0 * (real((double)w) / W) - 1) * cam->half_width;           // main.cpp:188
+            real y = (2.0 * (real((double)h) / H) - 1) * cam->half_width * H / W;   // main.cpp:189
             V3 dir = normalized(V3(x, y, 0) - camorg);                               // main.cpp:198
             V3 pof = dir * ((cam->focus_plane - camorg.z) / dir.z) + camorg;         // main.cpp:203
-            sink.acc = acc + 3 * pix;
+            sink.acc = as_real(acc + 3 * pix);
             sink.nhit = nhit + pix;
             for (int j = g->sample0; j < g->sample0 + g->spp; j++) {
                 RayCtx rc{g->seed, (uint64_t)h * (uint64_t)W + (uint64_t)w, (uint64_t)j};
@@ -1078,10 +1097,10 @@ uint64_t orc_photon_events(void *sp, const orc_photons *ph, int depth, int64_t f
     Sink sink;
     double dummy_acc[3] = {0, 0, 0};
     uint32_t dummy_hit = 0;
-    sink.acc = dummy_acc;
+    sink.acc = as_real(dummy_acc);
     sink.nhit = &dummy_hit;
     EventLog log;
-    log.out = out;
+    log.out = as_real(out);
     log.cap = cap;
     g_evlog = &log;
     V3 light = v3(ph->light);
@@ -1109,7 +1128,7 @@ int64_t orc_ppm(void *sp, const orc_camera *cam, const orc_grid *g, const orc_ph
     Sink sink;
     double dummy_acc[3] = {0, 0, 0};
     uint32_t dummy_hit = 0;
-    sink.acc = dummy_acc;
+    sink.acc = as_real(dummy_acc);
     sink.nhit = &dummy_hit;
     for (int h = g->row0; h < g->row0 + g->nrows; h++)
         for (int w = 0; w < W; w++) {
@@ -1172,5 +1191,15 @@ void orc_tonemap(const double *image, int W, int H, uint8_t *out) {
             counter++;
         }
 }
+
+#ifdef ORC_COUNT_FLOPS
+// ---- instrumented build only (liborc_flops.so): the counters of cgrt_flopcount.h.  Counting runs use ONE thread
+// (orc_set_threads(1), the default): the counters are thread-local and these two calls read the calling thread's. ----
+void orc_flop_reset(void) { std::memset(&g_fc, 0, sizeof(g_fc)); }
+// out[0..4] = additions/subtractions, multiplications, divisions, square roots, transcendental calls (pow sin cos atan exp)
+void orc_flop_counts(uint64_t *out) {
+    for (int k = 0; k < FC_N; k++) out[k] = g_fc.c[k];
+}
+#endif
 
 }  // extern "C"

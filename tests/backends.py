@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORC_SO = os.path.join(ORACLE_DIR, "liborc.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libcgrt_ref.so")
+ORC_FLOPS_SO = os.path.join(ORACLE_DIR, "liborc_flops.so")  # the instrumented build of the oracle (cgrt_flopcount.h)
 
 
 class OrcCamera(C.Structure):
@@ -47,11 +48,18 @@ def build_oracle():
 
 
 class Backend:
-    """prefix 'orc' -> oracle, 'ref' -> compiled reference."""
+    """prefix 'orc' -> oracle, 'ref' -> compiled reference, 'flops' -> the oracle's instrumented build (same entry points as
+    'orc' plus the operation counters: flop_reset() / flop_counts())."""
 
     def __init__(self, prefix):
+        self.counting = prefix == "flops"
+        if self.counting:
+            build_oracle()
+            if (not os.path.exists(ORC_FLOPS_SO)) or os.path.getmtime(ORC_FLOPS_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "cgrt_oracle.cpp")):
+                subprocess.check_call(["make", "-C", ORACLE_DIR, "liborc_flops.so"], stdout=subprocess.DEVNULL)
+            prefix = "orc"
         self.prefix = prefix
-        path = build_oracle() if prefix == "orc" else REF_SO
+        path = ORC_FLOPS_SO if self.counting else (build_oracle() if prefix == "orc" else REF_SO)
         self.lib = C.CDLL(path)
         L, p = self.lib, prefix
         f = lambda n: getattr(L, p + "_" + n)
@@ -101,7 +109,20 @@ class Backend:
 
     def set_threads(self, n):
         if self.prefix == "orc":
-            self.lib.orc_set_threads(int(n))
+            self.lib.orc_set_threads(1 if self.counting else int(n))  # the counters are per thread: counting runs use one
+
+    FLOP_FIELDS = ("add_sub", "mul", "div", "sqrt", "transcendental_calls")
+
+    def flop_reset(self):
+        self.lib.orc_flop_reset()
+
+    def flop_counts(self):
+        """dict of the operation counts since flop_reset(); `flops` = add_sub + mul + div + sqrt (each counted as one)."""
+        out = (C.c_uint64 * 8)()
+        self.lib.orc_flop_counts(out)
+        d = {k: int(out[i]) for i, k in enumerate(self.FLOP_FIELDS)}
+        d["flops"] = d["add_sub"] + d["mul"] + d["div"] + d["sqrt"]
+        return d
 
     def tonemap(self, image):
         """main.cpp:403-411 + gammaCorr: [H,W,3] float64 (row 0 = bottom) -> [H,W,3] uint8 (top row first)."""

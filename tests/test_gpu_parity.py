@@ -196,12 +196,16 @@ def test_bezier_intersect_vs_reference_golden(gpu_ready):
     nclose = np.abs(n[both] - g["bez_n"][both]).max(axis=1) < 1e-6
     print("bezier: hit agreement %.4f, len within 1e-6: %.4f, normal: %.4f, max |dlen| on close: %.3e"
           % (agree, close.mean(), nclose.mean(), np.abs(l[both] - g["bez_len"][both])[close].max()))
-    assert agree >= 0.995 and close.mean() >= 0.99 and nclose.mean() >= 0.99
+    # measured in round 3: flags 1.0000, len 1.0000, normal 1.0000, |dlen| <= 2.9e-14 on the 1 024 golden rays
+    assert agree == 1.0 and close.mean() >= 0.999 and nclose.mean() >= 0.999
 
 
-# Bars for scenes with a Bezier object = what round 3 MEASURED on MI355X minus a margin (VERDICT r2 "weak" 1): placeholder
-# until the first measured run of this round -- see bezier_report's output in gpurun_out/bezier_parity/.
-BEZ_SCENE_BAR = (0.995, 0.005)  # (fraction of pixels within 1e-4, relative ray-count gap)
+# Bars for scenes with a Bezier object = what round 3 MEASURED on MI355X minus a margin (VERDICT r2 "weak" 1).  Measured
+# (gpurun_out/bezier_parity/*.json, copied to profiles/r03_bezier_parity.json): bezier_scene 0 of 9 216 pixels miss 1e-4 and all
+# are bit-equal, rays 18 699 = 18 699; everything_at_once 0 of 12 288, rays 32 331 = 32 331; c5_shape 0 of 16 384.  The margin
+# allows for a handful of Newton outcomes flipping with another libm build (device pow/sin/cos are not glibc's): at most
+# 5 pixels in 10 000 and 5 rays in 10 000 -- one tenth of what round 2 accepted.
+BEZ_SCENE_BAR = (0.9995, 0.0005)  # (fraction of pixels within 1e-4, relative ray-count gap)
 
 
 def test_bezier_scene_vs_oracle(gpu_ready, orc):
