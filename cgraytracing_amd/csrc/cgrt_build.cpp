@@ -138,6 +138,7 @@ ObjRec blank_obj(int kind, const double sc[3], double refl, double transp) {
     o.transp = transp;
     o.tree = -1;
     o.tex = -1;
+    o.axis = -1;
     return o;
 }
 
@@ -652,6 +653,8 @@ int HostScene::add_plane(const double p[3], const double n[3], const double sc[3
     set3(o.a, p);
     set3(o.b, n);
     o.tex = tex < 0 ? -1 : tex;
+    for (int k = 0; k < 3; k++)  // exactly axis-aligned, exactly unit: the fast path of the scene walk
+        if ((n[k] == 1.0 || n[k] == -1.0) && n[(k + 1) % 3] == 0.0 && n[(k + 2) % 3] == 0.0) o.axis = k;
     if (tex >= 0 && textures[tex].isbump && std::fabs(n[1] - 1.0) < 1e-5) {
         // Displacement mesh of a bump-mapped floor (objects.h:482-503): one quad per 3x3 texel block,
         // split into triangles (a,b,c) and (d,b,c); heights 0.5*(1-exp(-3.3*luma)) (texture.h:28-35).

@@ -465,6 +465,7 @@ struct MeshResult {
     int nwide = 0, stack_need = 0;
     bool balanced = false;  // the fallback build was needed
     double centre[3] = {0, 0, 0}, r2 = -1.0;  // ObjRec.a / s0 (bounding sphere of the vertices, grown like the host's)
+    double bmax = 0;  // largest |coordinate| of a vertex (TreeRec::bmax)
     std::vector<double> cover;  // n_groups x (cx, cy, cz, r)
 };
 // tri9_host: n x 9 doubles; tris / otris / wnodes: device destinations (n, n, n records)
@@ -550,7 +551,10 @@ static int build_mesh_hierarchy(const double *tri9_host, int n, TriRec *tris, OT
     // bounding sphere (add_mesh_triangles) and cover spheres (cover_spheres)
     unsigned long long g[7];
     HIP_TRY(hipMemcpy(g, gbox.p, sizeof(g), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 3; k++) out.centre[k] = 0.5 * (dunkey(g[k]) + dunkey(g[3 + k]));
+    for (int k = 0; k < 3; k++) {
+        out.centre[k] = 0.5 * (dunkey(g[k]) + dunkey(g[3 + k]));
+        out.bmax = std::max(out.bmax, std::max(std::fabs(dunkey(g[k])), std::fabs(dunkey(g[3 + k]))));
+    }
     const double r = std::sqrt(dunkey(g[6])) + 1e-3;
     out.r2 = r * r * (1 + 1e-9);
     int depth = 0;

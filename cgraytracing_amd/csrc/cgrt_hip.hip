@@ -267,7 +267,12 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         tr.nnodes = ref_order ? (int32_t)t.nodes.size() : t.bvh_nodes;
         tr.noct = ref_order ? 1 : 8;
         tr.tri_level = (!ref_order && t.tri_level) ? 1 : 0;
-        tr.pad = 0;
+        {   // bound on |coordinate| of every box face (the fp32 box test's error term, cgrt_traverse.hpp Ray32): the vertices'
+            // largest magnitude, the growth of the boxes and a little more
+            double m = 0;
+            for (double v : t.tri9) m = std::max(m, std::fabs(v));
+            tr.bmax = (float)((m + 2 * kBoxPad) * (1 + 1e-6)) * (1.f + 1e-6f);
+        }
         tr.otri_begin = (int64_t)otris.size();
         if (tr.tri_level) otris.insert(otris.end(), t.otris.begin(), t.otris.end());
         tr.ntris = (int32_t)t.tris.size();
@@ -378,6 +383,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
                                                              const_cast<WideNodeRec *>(d.wnodes) + tr.wnode_begin, mr)))
                         return rc;
                     tr.nwide = mr.nwide;
+                    tr.bmax = (float)((mr.bmax + 2 * kBoxPad) * (1 + 1e-6)) * (1.f + 1e-6f);
                     t.dev_nwide = mr.nwide;
                     t.wide_stack = mr.stack_need;
                     t.dev_balanced = mr.balanced;

@@ -104,6 +104,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
         return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, o, d, inv, bound, n_node, n_tri);
     }
     const bool cached = aux.lnodes != nullptr && tr == sc.cached_tree;
+    const Ray32 r32 = make_ray32(o, inv, T.bmax);
     // the copy of the hierarchy whose children are ordered near-to-far for this ray's direction octant (only worth a
     // per-lane base address where order matters, i.e. for the pruned traversal)
     const int oct = (T.noct == 8 && opaque) ? ((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) : 0;
@@ -112,15 +113,15 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     if (opaque) {
         if (T.tri_level) {  // an opaque mesh: the 4-wide triangle-level hierarchy (an empty mesh has no nodes at all)
             if (T.nwide == 0) return none;
-            return tree_intersect_wide<STATS>(sc.wnodes + T.wnode_begin, sc.otris + T.otri_begin, o, d, inv, bound, n_node, n_tri,
+            return tree_intersect_wide<STATS>(sc.wnodes + T.wnode_begin, sc.otris + T.otri_begin, o, d, r32, bound, n_node, n_tri,
                                               aux.wstack);
         }
-        if (cached) return tree_intersect<STATS, true>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
-        return tree_intersect<STATS, true>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri);
+        if (cached) return tree_intersect<STATS, true>(aux.lnodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri);
+        return tree_intersect<STATS, true>(nodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri);
     }
     const NodeRec *tb = sc.tboxes + T.tbox_begin;
-    if (cached) return tree_intersect<STATS, false>(aux.lnodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, tb);
-    return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, inv, bound, n_node, n_tri, tb);
+    if (cached) return tree_intersect<STATS, false>(aux.lnodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri, tb);
+    return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri, tb);
 }
 
 template <bool TREES, bool BEZ, bool SPH, bool STATS>
@@ -160,8 +161,28 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
         } else if (kind == KIND_PLANE) {
             // Plane::intersect, objects.h:505-524
             const V3 pn = ld3(ob.b);
-            const V3 dd = ld3(ob.a) - o;
-            double len = dot(dd, pn) / dot(d, pn);
+            // len = ((p - o) . n) / (d . n).  For a normal that is exactly +-e_k the two dot products are +-(p_k - o_k) and
+            // +-d_k to the bit -- the other products are +-0 and adding +-0 to a non-zero double changes nothing -- and
+            // (-x) / (-y) rounds like x / y, so len is (p_k - o_k) / d_k: one subtraction and the division instead of three
+            // subtractions and two dot products (five planes a ray: ~60 of a plane-bound ray's instructions).  Only when that
+            // numerator or denominator is ZERO does the sign of the zero the general expression produces matter (+-inf, NaN):
+            // those lanes -- a ray exactly parallel to the plane, an origin exactly in it -- take the general expression.
+            const int ax = __builtin_amdgcn_readfirstlane(ob.axis);
+            double len;
+            if (ax >= 0) {
+                const double ok = ax == 0 ? o.x : (ax == 1 ? o.y : o.z), dk = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+                const double num = ob.a[ax] - ok;
+                len = num / dk;
+                const bool zero = (num == 0.0) || (dk == 0.0);
+                if (__ballot(zero) != 0ull) {
+                    const V3 dd = ld3(ob.a) - o;
+                    const double general = dot(dd, pn) / dot(d, pn);
+                    if (zero) len = general;
+                }
+            } else {
+                const V3 dd = ld3(ob.a) - o;
+                len = dot(dd, pn) / dot(d, pn);
+            }
             const bool ph = len > 0;
             V3 nrm = pn;
             if (TREES) {

@@ -26,6 +26,45 @@
 // quotients with 0 and 1.  For finite non-zero det1 the sign and "<= 1" tests on correctly rounded quotients
 // are equivalent to the sign / magnitude tests below (DESIGN.md "triangle test"), so only an accepted hit pays
 // for a division (len = det2/det1, the same correctly rounded quotient).
+// ---- the box test in single precision --------------------------------------------------------------------------------
+// A box test only has to accept a SUPERSET of the boxes the ray really touches (above), and a ray's entry distance into a box
+// is only ever used as a LOWER bound (pruning).  The boxes are fp32 already; evaluating the slabs in fp32 too halves the
+// instructions of a node visit (no conversions, two-wide packed subtract / multiply) -- provided every rounding error is
+// covered.  For one face at coordinate b the computed crossing is
+//     t = fl32( fl32(b - o32) * i32 ),   o32 = fl32(o),  i32 = fl32(1/d)
+// = (b_eq - o) / d for a plane at b_eq with |b_eq - b| <= u (3.01 |b| + 4.02 |o|), u = 2^-24 (expand the three roundings and
+// the two conversions; 1/d itself is the correctly rounded fp64 quotient).  So the test is run against boxes grown, per ray
+// and per axis, by e = 8 u (|o| + bmax) >= twice that bound, bmax >= |b| for every face of the tree (TreeRec::bmax): the
+// lower faces see the origin o32 + e, the upper faces o32 - e, at no cost per box.  Then every computed slab interval
+// CONTAINS the true one of the stored (1e-4-grown) box: accepted boxes are a superset, computed entry distances lower
+// bounds.  d_k = 0 gives i32 = +-inf and intervals (-inf, +inf) or empty exactly as in fp64 (0 * inf = NaN arises only for
+// an origin that the growth puts exactly on a face, i.e. a true origin outside the stored box: NaN loses every min / max,
+// the box is rejected, correctly).  Coordinates are assumed to stay below ~1e30 in magnitude (no fp32 overflow).
+struct Ray32 {
+    float olo[3], ohi[3], inv[3];
+};
+__device__ __forceinline__ Ray32 make_ray32(V3 o, V3 inv, float bmax) {
+    Ray32 r;
+    const double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float o32 = (float)oo[k];
+        const float e = (fabsf(o32) + bmax) * 4.8e-7f + 1e-30f;  // 8 * 2^-24 = 4.77e-7
+        r.olo[k] = o32 + e;
+        r.ohi[k] = o32 - e;
+        r.inv[k] = (float)ii[k];
+    }
+    return r;
+}
+// entry / exit of the grown box {lo, hi}: tn <= true entry distance, tf >= true exit distance
+__device__ __forceinline__ void slab32(const Ray32 &r, float lx, float ly, float lz, float hx, float hy, float hz, float &tn, float &tf) {
+    const float ax = (lx - r.olo[0]) * r.inv[0], bx = (hx - r.ohi[0]) * r.inv[0];
+    const float ay = (ly - r.olo[1]) * r.inv[1], by = (hy - r.ohi[1]) * r.inv[1];
+    const float az = (lz - r.olo[2]) * r.inv[2], bz = (hz - r.ohi[2]) * r.inv[2];
+    tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+}
+
 struct TreeHit {
     double len;
     int tri;      // absolute index into tris[]
@@ -47,8 +86,9 @@ struct TreeHit {
 // form (tree_intersect_wide below); this routine serves transparent owners (PRUNE = false) and CGRT_TREE=ref.
 template <bool STATS, bool PRUNE>
 __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ nodes, const TriRec *__restrict__ tris,
-                                                  int nnodes, V3 o, V3 d, V3 inv, double bound, uint32_t &n_node,
+                                                  int nnodes, V3 o, V3 d, const Ray32 &r32, double bound, uint32_t &n_node,
                                                   uint32_t &n_tri, const NodeRec *__restrict__ tboxes = nullptr) {
+    float bound32 = PRUNE ? __double2float_ru(bound) : 0.f;  // >= bound: an entry distance above it is above bound
     TreeHit r;
     r.len = kInf;
     r.tri = -1;
@@ -65,20 +105,9 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             const float4 q0 = reinterpret_cast<const float4 *>(nodes + i)[0];  // lo.x lo.y lo.z hi.x
             const float4 q1 = reinterpret_cast<const float4 *>(nodes + i)[1];  // hi.y hi.z skip leaf
             if (STATS) n_node++;
-            double t1, t2, tn, tf;
-            t1 = ((double)q0.x - o.x) * inv.x;
-            t2 = ((double)q0.w - o.x) * inv.x;
-            tn = fmin(t1, t2);
-            tf = fmax(t1, t2);
-            t1 = ((double)q0.y - o.y) * inv.y;
-            t2 = ((double)q1.x - o.y) * inv.y;
-            tn = fmax(tn, fmin(t1, t2));
-            tf = fmin(tf, fmax(t1, t2));
-            t1 = ((double)q0.z - o.z) * inv.z;
-            t2 = ((double)q1.y - o.z) * inv.z;
-            tn = fmax(tn, fmin(t1, t2));
-            tf = fmin(tf, fmax(t1, t2));
-            const bool touch = (tf > 0.0) && (tn <= tf) && !(PRUNE && tn > bound);
+            float tn, tf;
+            slab32(r32, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn, tf);
+            const bool touch = (tf > 0.f) && (tn <= tf) && !(PRUNE && tn > bound32);
             const int leaf = __float_as_int(q1.w);
             if (!touch) {
                 i = __float_as_int(q1.z);
@@ -106,20 +135,9 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             for (int k = 0; k < leaf_cnt_tris; k++) {
                 const float4 q0 = reinterpret_cast<const float4 *>(bp + k)[0];  // lo.x lo.y lo.z hi.x
                 const float2 q1 = reinterpret_cast<const float2 *>(bp + k)[2];  // hi.y hi.z
-                double t1, t2, tn, tf;
-                t1 = ((double)q0.x - o.x) * inv.x;
-                t2 = ((double)q0.w - o.x) * inv.x;
-                tn = fmin(t1, t2);
-                tf = fmax(t1, t2);
-                t1 = ((double)q0.y - o.y) * inv.y;
-                t2 = ((double)q1.x - o.y) * inv.y;
-                tn = fmax(tn, fmin(t1, t2));
-                tf = fmin(tf, fmax(t1, t2));
-                t1 = ((double)q0.z - o.z) * inv.z;
-                t2 = ((double)q1.y - o.z) * inv.z;
-                tn = fmax(tn, fmin(t1, t2));
-                tf = fmin(tf, fmax(t1, t2));
-                if ((tf > 0.0) && (tn <= tf)) cand |= 1u << k;
+                float tn, tf;
+                slab32(r32, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn, tf);
+                if ((tf > 0.f) && (tn <= tf)) cand |= 1u << k;
             }
             // pass 2: the exact tests, each lane on ITS candidates in ascending order (the leaf's order, objects.h:273-289):
             // the wave runs as many rounds as its busiest lane has candidates instead of one round per triangle of the leaf
@@ -186,7 +204,10 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
                 r_leaf = leaf_begin;
             }
             r.counter += leaf_cnt;
-            if (PRUNE && r.len < bound) bound = r.len;
+            if (PRUNE && r.len < bound) {
+                bound = r.len;
+                bound32 = __double2float_ru(bound);
+            }
         }
     }
     return r;
@@ -209,8 +230,9 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
 // the same (len, triangle).
 template <bool STATS>
 __device__ __forceinline__ TreeHit tree_intersect_wide(const WideNodeRec *__restrict__ wn, const OTriRec *__restrict__ otris, V3 o,
-                                                       V3 d, V3 inv, double bound, uint32_t &n_node, uint32_t &n_tri,
+                                                       V3 d, const Ray32 &r32, double bound, uint32_t &n_node, uint32_t &n_tri,
                                                        uint2 *lstack = nullptr) {
+    float bound32 = __double2float_ru(bound);  // >= bound: an entry distance above it is above bound
     TreeHit r;
     r.len = kInf;
     r.tri = -1;
@@ -230,7 +252,7 @@ __device__ __forceinline__ TreeHit tree_intersect_wide(const WideNodeRec *__rest
         while (sp > 0) {
             --sp;
             const uint2 e = (lstack && sp < kWideLdsDepth) ? lstack[sp * nt + tid] : stk[sp];
-            if (!((double)__uint_as_float(e.y) > bound)) return (int32_t)e.x;
+            if (!(__uint_as_float(e.y) > bound32)) return (int32_t)e.x;
         }
         return kWideNone;
     };
@@ -243,27 +265,16 @@ __device__ __forceinline__ TreeHit tree_intersect_wide(const WideNodeRec *__rest
             const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
             const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
             const int32_t rf[4] = {ref.x, ref.y, ref.z, ref.w};
-            double tn4[4];
+            float tn4[4];
             bool hit4[4];
-            double best_tn = kInf * kInf;  // +inf
+            float best_tn = __int_as_float(0x7f800000);  // +inf
             int32_t best_ref = kWideNone;
             int best = -1;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                double t1, t2, tn, tf;
-                t1 = ((double)lx[k] - o.x) * inv.x;
-                t2 = ((double)hx[k] - o.x) * inv.x;
-                tn = fmin(t1, t2);
-                tf = fmax(t1, t2);
-                t1 = ((double)ly[k] - o.y) * inv.y;
-                t2 = ((double)hy[k] - o.y) * inv.y;
-                tn = fmax(tn, fmin(t1, t2));
-                tf = fmin(tf, fmax(t1, t2));
-                t1 = ((double)lz[k] - o.z) * inv.z;
-                t2 = ((double)hz[k] - o.z) * inv.z;
-                tn = fmax(tn, fmin(t1, t2));
-                tf = fmin(tf, fmax(t1, t2));
-                const bool touch = (rf[k] != kWideNone) && (tf > 0.0) && (tn <= tf) && !(tn > bound);
+                float tn, tf;
+                slab32(r32, lx[k], ly[k], lz[k], hx[k], hy[k], hz[k], tn, tf);
+                const bool touch = (rf[k] != kWideNone) && (tf > 0.f) && (tn <= tf) && !(tn > bound32);
                 if (STATS && rf[k] != kWideNone) n_node++;
                 tn4[k] = tn;
                 hit4[k] = touch;
@@ -275,7 +286,7 @@ __device__ __forceinline__ TreeHit tree_intersect_wide(const WideNodeRec *__rest
             }
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (hit4[k] && k != best) push(make_uint2((uint32_t)rf[k], __float_as_uint(__double2float_rd(tn4[k]))));
+                if (hit4[k] && k != best) push(make_uint2((uint32_t)rf[k], __float_as_uint(tn4[k])));
             nxt = best >= 0 ? best_ref : pop();
         }
         if (nxt == kWideNone) break;
@@ -305,7 +316,10 @@ __device__ __forceinline__ TreeHit tree_intersect_wide(const WideNodeRec *__rest
                     }
                 }
             }
-            if (r.len < bound) bound = r.len;
+            if (r.len < bound) {
+                bound = r.len;
+                bound32 = __double2float_ru(bound);
+            }
         }
         nxt = pop();
     }

@@ -31,7 +31,9 @@ struct ObjRec {
     int32_t tree;         // mesh: tree index; plane: bump tree index or -1
     int32_t tex;          // plane: texture index or -1
     int32_t aux;          // mesh: objtype (objects.h:434); bezier: index into beziers[]
-    int32_t pad0, pad1, pad2, pad3;
+    int32_t axis;         // plane: k = 0, 1, 2 when the normal is exactly +-e_k (two components +-0, one +-1), else -1 -- such a
+                          // plane's `len` is (a_k - o_k) / d_k, the same double the general expression gives (cgrt_scene_walk.hpp)
+    int32_t pad1, pad2, pad3;
 };
 static_assert(sizeof(ObjRec) == 128, "ObjRec layout");
 
@@ -91,7 +93,7 @@ struct TreeRec {
                          // children near-to-far) for the SAH hierarchy, 1 for the reference-order tree
     int32_t tri_level;   // 1: the hierarchy is over single triangles (opaque owner), leaves index otris[]; 0: over the
                          // reference's leaves, leaves index tris[]
-    int32_t pad;
+    float bmax;          // >= |coordinate| of every box face of this tree (the single-precision box test's error bound, Ray32)
     int64_t tbox_begin;  // into tboxes[]: one box per triangle of tris[], same order
     int64_t wnode_begin; // tri_level only: into wnodes[] (nwide records, root first); nwide == 0: walk nodes[] instead
     int32_t nwide;
