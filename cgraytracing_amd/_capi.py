@@ -6,9 +6,19 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import sys
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# CGRT_LIB: load another build of the same ABI instead (experiments only, e.g. tools/fma_experiment.py's libcgrt_fma.so)
-LIB_PATH = os.environ.get("CGRT_LIB") or os.path.join(_HERE, "libcgrt.so")
+CGRT_VERSION = 112  # include/cgrt.h: the ABI this binding was written against
+# Development hook: CGRT_LIB names another build of the same ABI (make exp / make fma: other occupancy or contraction choices)
+# and is honoured ONLY together with CGRT_DEV_LIBS=1 -- a stray variable must not swap the product's library.
+LIB_PATH = os.path.join(_HERE, "libcgrt.so")
+if os.environ.get("CGRT_LIB"):
+    if os.environ.get("CGRT_DEV_LIBS") == "1":
+        LIB_PATH = os.environ["CGRT_LIB"]
+        print("cgraytracing_amd: DEVELOPMENT library %s (CGRT_LIB + CGRT_DEV_LIBS=1)" % LIB_PATH, file=sys.stderr)
+    else:
+        print("cgraytracing_amd: CGRT_LIB ignored (set CGRT_DEV_LIBS=1 to load a development build)", file=sys.stderr)
 
 CGRT_OK = 0
 CGRT_NCOUNTERS = 8
@@ -121,7 +131,8 @@ def lib():
         # Load order matters where PyTorch is in the process: libtorch_hip needs "libamdhip64.so" (its bundled copy, found by
         # RPATH) while libcgrt.so needs "libamdhip64.so.7".  With torch first, our NEEDED entry matches the SONAME of the copy
         # already loaded and the process has ONE HIP runtime; with libcgrt.so first, torch's name matches nothing loaded, a
-        # second runtime comes in and one of the two then finds "no ROCm-capable device".  So torch, when importable, goes first.
+        # second runtime comes in and one of the two then finds "no ROCm-capable device".  So torch, when importable, goes first
+        # -- deliberately, also for the torch-free entry points (trace_grid_host, ppm_render): the cost is torch's import time.
         try:
             import torch  # noqa: F401
         except ImportError:
@@ -131,6 +142,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.cgrt_version() != CGRT_VERSION:  # same symbols, other struct layouts: refuse rather than corrupt memory
+            raise ImportError("cgraytracing_amd: %s is ABI version %d, this binding needs %d -- rebuild it (make -C cgraytracing_amd/csrc)"
+                              % (LIB_PATH, L.cgrt_version(), CGRT_VERSION))
         _lib = L
     return _lib
 

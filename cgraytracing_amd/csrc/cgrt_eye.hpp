@@ -49,8 +49,12 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? TG::stack_bytes : 0));  // n_objs records
     // BEZ: one BezLds per wave behind the object list (16-byte aligned: ObjRec is 128 B)
-    unsigned char *lrest = reinterpret_cast<unsigned char *>(lobjs + sc.n_objs);
+    unsigned char *lrest = reinterpret_cast<unsigned char *>(lobjs + sc.n_lds);
     LdsAux aux;
+    if (sc.n_objs > sc.n_lds) {  // one staging record per wave for the objects beyond the LDS list
+        aux.spill = reinterpret_cast<ObjRec *>(lrest) + (threadIdx.x >> 6);
+        lrest += (NT / 64) * sizeof(ObjRec);
+    }
     aux.bl = BEZ ? reinterpret_cast<volatile BezLds *>(lrest) + (threadIdx.x >> 6) : nullptr;
     if (BEZ) lrest += (NT / 64) * sizeof(BezLds);
     // TREES: node cache behind that (32-byte records, region is 16-byte aligned)
@@ -71,7 +75,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.objs);
         uint4 *dst = reinterpret_cast<uint4 *>(lobjs);
-        const int n16 = sc.n_objs * (int)(sizeof(ObjRec) / 16);
+        const int n16 = sc.n_lds * (int)(sizeof(ObjRec) / 16);
         for (int k = threadIdx.x; k < n16; k += NT) dst[k] = src[k];
     }
     __syncthreads();
@@ -252,12 +256,12 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
         // is wave-uniform, so its control flow stays scalar.
         RayKey rk{k_smp, path, false, 0u};
         const SceneHit hit =
-            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
+            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
         if (have) {
             my_rays++;
             have = false;
             if (hit.id >= 0) {
-                const ObjRec &ob = lobjs[hit.id];
+                const ObjMat ob = load_mat(lobjs, sc.n_lds, sc.objs, hit.id);
                 const V3 P = o + d * hit.t;  // main.cpp:68
                 V3 n = hit.n;
                 const V3 n_old = n;
@@ -266,7 +270,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                     n = -n;
                     into = false;
                 }
-                V3 f = ld3(ob.col);  // getSurfaceColor
+                V3 f = ob.col;  // getSurfaceColor
                 if (ob.kind == KIND_PLANE && ob.tex >= 0) {
                     V3 c;
                     if (texture_color(sc.texs[ob.tex], sc.texels, P, c)) f = c;  // objects.h:533-539
@@ -860,7 +864,7 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     DeviceScene one = sc;
     RayKey rk{keys ? keys[ii] : 0ull, 1, true, 0u};
     const LdsAux aux{&bl, nullptr};
-    SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, one, o, d, rk, on, aux, a, b);
+    SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, 1, one, o, d, rk, on, aux, a, b);
     if (!on) return;
     hit[i] = h.id >= 0 ? 1 : 0;
     len[i] = h.t;

@@ -61,7 +61,6 @@ struct GridParams {
 static constexpr int kTileW = 32, kTileH = 8, kThreads = 256;
 static constexpr int kWaveTileW = 16, kWaveTileH = 4;  // one pixel per lane
 static constexpr uint32_t kNoWaveTile = 0xffffffffu;
-static constexpr int kMaxObjs = 96;  // top-level objects staged in LDS (12 KiB)
 // Pending refracted rays (main.cpp:157) of a lane, newest last:
 //   * a glass hit whose children are leaves of the recursion (depth_left == 2) keeps the refracted child in
 //     REGISTERS (it is consumed right after the reflected child, before any other push) -- in a full glass tree

@@ -161,7 +161,7 @@ void cgrt_scene_destroy(cgrt_scene *s) {
 static int added(cgrt_scene *s, int r) {
     if (r == -2) return fail(CGRT_ERR_IO, s->host.error);
     if (r < 0) return fail(CGRT_ERR_INVALID, s->host.error);
-    if ((int)s->host.objs.size() > kMaxObjs) return fail(CGRT_ERR_LIMIT, "more than 96 top-level objects");
+    if ((int)s->host.objs.size() > kMaxObjs) return fail(CGRT_ERR_LIMIT, "more than 2^20 top-level objects");
     return r;
 }
 
@@ -416,6 +416,11 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         return rc;
     }
     d.n_objs = (int32_t)H.objs.size();
+    // objects resident in LDS: all of them up to kLdsObjsMax (CGRT_LDS_OBJS, read at every commit, lowers that for measurements
+    // and tests of the spill path)
+    d.n_lds = std::min(d.n_objs, kLdsObjsMax);
+    if (const char *e = std::getenv("CGRT_LDS_OBJS")) d.n_lds = std::max(0, std::min(d.n_lds, std::atoi(e)));
+    d.pad_lds_ = 0;
     d.n_trees = (int32_t)trees.size();
     d.n_texs = (int32_t)texs.size();
     d.n_beziers = (int32_t)H.beziers.size();
@@ -586,6 +591,14 @@ int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int3
     return CGRT_OK;
 }
 
+// A launch whose dynamic LDS exceeds the default allowance asks for it first (a CU has 160 KiB; scenes with hundreds of
+// top-level objects).  The attribute is per kernel; setting it again is harmless.
+#define BIG_LDS(kernel, bytes)                                                                                                 \
+    do {                                                                                                                      \
+        if ((bytes) > ((size_t)48 << 10))                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10); \
+    } while (0)
+
 // Which instantiation of trace_grid_kernel a launch uses (chosen from the scene's materials and the camera).
 struct GridVariant {
     bool trees, bez, dof, glass, sph, stats;
@@ -684,7 +697,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const int tile_blocks = one_wave ? tile_grid_blocks(g.W, g.rows, false, TileGeom<64>::W, TileGeom<64>::H)
                                      : tile_grid_blocks(g.W, g.rows, g.xcd_tiles != 0);
     const dim3 natural_dim((unsigned)(tile_blocks * g.chunks)), block(one_wave ? 64 : kThreads);
-    size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
+    size_t lds = obj_list_lds(s->dev, waves_per_block);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto *cnt = reinterpret_cast<unsigned long long *>(counters);
     // launch on the scene's device whatever the caller's current device is (one host thread may drive several GPUs)
@@ -793,8 +806,8 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         constexpr bool SCHED = decltype(sched_tag)::value;
 #define LAUNCH(T, B, D, G, P, S)                                                                                              \
     do {                                                                                                                      \
-        if (SCHED) hipLaunchKernelGGL((trace_grid_sched_kernel<T, B, D, G, P, S, 256>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); \
-        else hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_);     \
+        if (SCHED) { BIG_LDS((trace_grid_sched_kernel<T, B, D, G, P, S, 256>), lds); hipLaunchKernelGGL((trace_grid_sched_kernel<T, B, D, G, P, S, 256>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); } \
+        else { BIG_LDS((trace_grid_kernel<T, B, D, G, P, S>), lds); hipLaunchKernelGGL((trace_grid_kernel<T, B, D, G, P, S>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); }     \
     } while (0)
 #define LAUNCH_DG(T, B, P, S)                                      \
     do {                                                           \
@@ -804,8 +817,8 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         if (bez) {  // Bezier scenes share the tree-capable variants (the tree code is skipped when there is no tree)
 #define LAUNCH1(D, G)                                                                                                          \
     do {                                                                                                                       \
-        if (SCHED) hipLaunchKernelGGL((trace_grid_sched_kernel<true, true, D, G, false, false, 64>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); \
-        else hipLaunchKernelGGL((trace_grid_kernel<true, true, D, G, false, false, false, 64>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_);    \
+        if (SCHED) { BIG_LDS((trace_grid_sched_kernel<true, true, D, G, false, false, 64>), lds); hipLaunchKernelGGL((trace_grid_sched_kernel<true, true, D, G, false, false, 64>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); } \
+        else { BIG_LDS((trace_grid_kernel<true, true, D, G, false, false, false, 64>), lds); hipLaunchKernelGGL((trace_grid_kernel<true, true, D, G, false, false, false, 64>), gd, block, lds, st, s->dev, gp, rgb_, nhit_, cnt_); }    \
     } while (0)
             if (dof) { if (glass) LAUNCH1(true, true); else LAUNCH1(true, false); }
             else     { if (glass) LAUNCH1(false, true); else LAUNCH1(false, false); }
@@ -862,14 +875,18 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
             gl.timeline = nullptr;
             HIP_TRY(hipEventRecord(s->ev_fork, st));
             HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
-            size_t lds_light = (size_t)s->dev.n_objs * sizeof(ObjRec);
+            size_t lds_light = obj_list_lds(s->dev, kThreads / 64);
             const bool ltrees = s->dev.light_trees != 0;  // bump-mapped planes: the tree-capable variant (same LDS carve-up as the main launch's)
             if (ltrees && s->dev.cached_tree >= 0) lds_light += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
             if (ltrees && s->dev.has_wide) lds_light += (size_t)kThreads * kWideLdsDepth * sizeof(uint2);
             const dim3 gd_light((unsigned)tile_grid_blocks(g.W, g.rows, false));
             gl.xcd_tiles = 0;
-#define LIGHT(T, D) hipLaunchKernelGGL((trace_grid_kernel<T, false, D, false, false, false>), gd_light, dim3(kThreads), lds_light, \
-                                       s->aux_stream, s->dev, gl, rgb, nhit, cnt)
+#define LIGHT(T, D)                                                                                                           \
+    do {                                                                                                                      \
+        BIG_LDS((trace_grid_kernel<T, false, D, false, false, false>), lds_light);                                             \
+        hipLaunchKernelGGL((trace_grid_kernel<T, false, D, false, false, false>), gd_light, dim3(kThreads), lds_light, s->aux_stream, \
+                           s->dev, gl, rgb, nhit, cnt);                                                                       \
+    } while (0)
             if (ltrees) { if (dof) LIGHT(true, true); else LIGHT(true, false); }
             else        { if (dof) LIGHT(false, true); else LIGHT(false, false); }
 #undef LIGHT
@@ -982,10 +999,12 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     HIP_TRY(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
     g.xcd_tiles = (s->dev.has_mesh && !s->dev.has_bezier) ? 1 : 0;
     const dim3 grid_dim((unsigned)tile_grid_blocks(g.W, g.rows, g.xcd_tiles != 0)), block(kThreads);
-    const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec) + kStackBytes + (kThreads / 64) * sizeof(BezLds) +
+    const size_t lds = obj_list_lds(s->dev, kThreads / 64) + kStackBytes + (kThreads / 64) * sizeof(BezLds) +
                        (s->dev.cached_tree >= 0 ? (size_t)s->dev.cached_nodes * sizeof(NodeRec) : 0);
     HitpointSink sink{d_rec, d_cnt, (unsigned long long)cap};
     // the most general variant serves every scene; capture is a verification / hand-off path, not the hot path
+    BIG_LDS((trace_grid_kernel<true, true, true, true, false, false, true>), lds);
+    BIG_LDS((trace_grid_kernel<true, true, false, true, false, false, true>), lds);
     if (cam->lens_radius > 0)
         hipLaunchKernelGGL((trace_grid_kernel<true, true, true, true, false, false, true>), grid_dim, block, lds, 0,
                            s->dev, g, d_rgb, (uint32_t *)nullptr, (unsigned long long *)nullptr, sink);

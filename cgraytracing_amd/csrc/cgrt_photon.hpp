@@ -124,14 +124,16 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.objs);
         uint4 *dst = reinterpret_cast<uint4 *>(lobjs);
-        const int n16 = sc.n_objs * (int)(sizeof(ObjRec) / 16);
+        const int n16 = sc.n_lds * (int)(sizeof(ObjRec) / 16);
         for (int k = threadIdx.x; k < n16; k += kThreads) dst[k] = src[k];
     }
     __syncthreads();
+    unsigned char *lrest = lds_raw + obj_list_lds(sc, kThreads / 64);
     // BEZ: one BezLds per wave behind the object list; the Newton starts continue the photon's own stream
-    LdsAux aux{BEZ ? reinterpret_cast<volatile BezLds *>(lobjs + sc.n_objs) + (threadIdx.x >> 6) : nullptr, nullptr};
+    LdsAux aux{BEZ ? reinterpret_cast<volatile BezLds *>(lrest) + (threadIdx.x >> 6) : nullptr, nullptr};
+    if (sc.n_objs > sc.n_lds) aux.spill = lobjs + sc.n_lds + (threadIdx.x >> 6);
     // without Bezier objects: the first entries of the 4-wide walk's stack live in LDS behind the object list, as in the eye pass
-    if (!BEZ && photon_lds_stack(sc)) aux.wstack = reinterpret_cast<uint2 *>(lobjs + sc.n_objs);
+    if (!BEZ && photon_lds_stack(sc)) aux.wstack = reinterpret_cast<uint2 *>(lrest);
     const int p = blockIdx.x * kThreads + threadIdx.x;
     bool alive = p < pa.count;
     Stream rs(stream_key(pa.seed, (uint64_t)(pa.first + (alive ? p : 0)), 0, 0x70686f74ull));
@@ -147,14 +149,14 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace
     for (int seg = 0; seg < pa.max_depth; seg++) {
         if (__ballot(alive) == 0ull) break;
         RayKey rk{rs.key, 1, true, rs.n};
-        const SceneHit hit = intersect_scene<true, BEZ, false, false>(lobjs, sc.n_objs, sc, o, d, rk, alive, aux, dn, dt);
+        const SceneHit hit = intersect_scene<true, BEZ, false, false>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, alive, aux, dn, dt);
         if (BEZ) rs.n = rk.n0;
         if (!alive) continue;
         if (hit.id < 0) {
             alive = false;
             continue;
         }
-        const ObjRec &ob = lobjs[hit.id];
+        const ObjMat ob = load_mat(lobjs, sc.n_lds, sc.objs, hit.id);
         const V3 P = o + d * hit.t;
         V3 n = hit.n;
         const V3 n_old = n;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace
             n = -n;
             into = false;
         }
-        V3 f = ld3(ob.col);
+        V3 f = ob.col;
         if (ob.kind == KIND_PLANE && ob.tex >= 0) {
             V3 c;
             if (texture_color(sc.texs[ob.tex], sc.texels, P, c)) f = c;
@@ -494,7 +496,11 @@ int sort_pairs(SortTemp &tmp, unsigned long long *kin, unsigned long long *kout,
 
 void launch_photon_trace(const cgrt_scene *s, const PhotonArgs &pa, double *events, unsigned char *valid, hipStream_t st = 0) {
     const dim3 grid((pa.count + kThreads - 1) / kThreads), block(kThreads);
-    const size_t lds = (size_t)s->dev.n_objs * sizeof(ObjRec);
+    const size_t lds = obj_list_lds(s->dev, kThreads / 64);
+    if (lds > ((size_t)48 << 10)) {  // more than the default dynamic-LDS allowance: ask for it (a CU has 160 KiB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photon_trace_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photon_trace_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+    }
     if (s->dev.has_bezier)
         hipLaunchKernelGGL(photon_trace_kernel<true>, grid, block, lds + (kThreads / 64) * sizeof(BezLds), st, s->dev, pa, events,
                            valid);

@@ -57,11 +57,10 @@ struct RayKey {
 };
 
 // Sphere::intersect, objects.h:45-68: the hit distance, or +inf-like kInf (never < nearest) on a miss
-__device__ __forceinline__ double sphere_len(const ObjRec &ob, V3 o, V3 d) {
-    const V3 l = ld3(ob.a) - o;
+__device__ __forceinline__ double sphere_len(V3 centre, double r2, V3 o, V3 d) {
+    const V3 l = centre - o;
     const double tca = dot(l, d);
     const double l2 = dot(l, l);
-    const double r2 = ob.s0;
     double len = kInf;
     if (!(tca < 0 && l2 > r2)) {
         const double d2 = l2 - tca * tca;
@@ -73,6 +72,39 @@ __device__ __forceinline__ double sphere_len(const ObjRec &ob, V3 o, V3 d) {
     }
     return len;
 }
+__device__ __forceinline__ double sphere_len(const ObjRec &ob, V3 o, V3 d) { return sphere_len(ld3(ob.a), ob.s0, o, d); }
+
+// The first 56 bytes of an ObjRec -- what the sphere loop needs of an object that is not in LDS (one scalar load)
+struct ObjHead {
+    double a[3], b[3], s0;
+};
+// What shading needs of the object a lane has hit: from LDS, or for an object beyond the LDS list from the uploaded array
+struct ObjMat {
+    V3 col;
+    double refl, transp;
+    int32_t kind, tex;
+};
+__device__ __forceinline__ ObjMat load_mat(const ObjRec *__restrict__ lobjs, int n_lds, const ObjRec *__restrict__ gobjs, int id) {
+    ObjMat m;
+    if (id < n_lds) {
+        const ObjRec &r = lobjs[id];
+        m.col = ld3(r.col); m.refl = r.refl; m.transp = r.transp; m.kind = r.kind; m.tex = r.tex;
+    } else {
+        const ObjRec &r = gobjs[id];
+        m.col = ld3(r.col); m.refl = r.refl; m.transp = r.transp; m.kind = r.kind; m.tex = r.tex;
+    }
+    return m;
+}
+__device__ __forceinline__ V3 load_centre(const ObjRec *__restrict__ lobjs, int n_lds, const ObjRec *__restrict__ gobjs, int id) {
+    if (id < n_lds) return ld3(lobjs[id].a);
+    return ld3(gobjs[id].a);
+}
+
+// bytes of LDS the object list takes in a workgroup: the resident records and, when some objects are not resident, one staging
+// record per wave
+__host__ __device__ inline size_t obj_list_lds(const DeviceScene &sc, int waves) {
+    return ((size_t)sc.n_lds + (sc.n_objs > sc.n_lds ? (size_t)waves : 0)) * sizeof(ObjRec);
+}
 
 // One small tree (<= kNodeCache nodes: the bunny's 255, a coarse bump floor) is staged whole in LDS by every workgroup:
 // traversal is latency-bound on dependent node fetches, and an LDS read costs ~100 cycles against ~500-800 for L1/L2.
@@ -83,6 +115,7 @@ struct LdsAux {
     volatile BezLds *bl;    // this wave's Bezier scratch (BEZ variants) or nullptr
     const NodeRec *lnodes;  // LDS copy of tree sc.cached_tree's nodes, or nullptr
     uint2 *wstack = nullptr;  // LDS part of the 4-wide walk's stack ([entry][thread]), or nullptr
+    ObjRec *spill = nullptr;  // this wave's staging record for objects beyond the LDS list (scenes with more than kLdsObjsMax objects)
 };
 
 // tree traversal entry; `on` = this lane really has a ray for this tree (all lanes of the wave call it).
@@ -125,7 +158,9 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
 }
 
 template <bool TREES, bool BEZ, bool SPH, bool STATS>
-__device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_objs, const DeviceScene &sc,
+// objs[0 .. n_lds): the LDS-resident list; objects n_lds .. n_objs-1 (scenes with more than kLdsObjsMax objects) come from
+// sc.objs, in the same order, so ties still go to the earlier object (main.cpp:57).
+__device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_lds, int n_objs, const DeviceScene &sc,
                                                     V3 o, V3 d, RayKey &rk, bool on, const LdsAux &aux,
                                                     uint32_t &n_node, uint32_t &n_tri) {
     SceneHit best;
@@ -135,21 +170,40 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
     int nsrc = 0;  // 0: sphere (normal derived after the loop), 1: stored in best.n
     if (SPH) {
         // scenes made of spheres only: no kind dispatch, nothing but (t, id) carried round the loop
-        for (int i = 0; i < n_objs; i++) {
+        for (int i = 0; i < n_lds; i++) {
             const double len = sphere_len(objs[i], o, d);
             if (len < best.t) {
                 best.t = len;
                 best.id = i;
             }
         }
-        if (best.id >= 0) best.n = normalized((o + d * best.t) - ld3(objs[best.id].a));  // objects.h:65-66
+        for (int i = n_lds; i < n_objs; i++) {  // beyond the LDS list: one scalar load per object and wave (s_load_dwordx16)
+            const ObjHead h = load_uniform(reinterpret_cast<const ObjHead *>(sc.objs + i));
+            const double len = sphere_len(mk(h.a[0], h.a[1], h.a[2]), h.s0, o, d);
+            if (len < best.t) {
+                best.t = len;
+                best.id = i;
+            }
+        }
+        if (best.id >= 0) best.n = normalized((o + d * best.t) - load_centre(objs, n_lds, sc.objs, best.id));  // objects.h:65-66
         return best;
     }
     // 1/d for the box tests: three fp64 divisions (~100 instructions), paid only by waves that reach a tree
     V3 inv = mk(0, 0, 0);
     bool inv_ready = false;  // wave-uniform
     for (int i = 0; i < n_objs; i++) {
-        const ObjRec &ob = objs[i];
+        const ObjRec *obp = objs + i;
+        if (i >= n_lds) {
+            // beyond the LDS list: the record is staged in this wave's LDS slot (eight 16-byte pieces) and read from there,
+            // so that the body below exists once.  LDS operations of one wave execute in order; the fence keeps the
+            // compiler from moving the reads of other lanes above the writes.
+            if ((threadIdx.x & 63) < 8)
+                reinterpret_cast<uint4 *>(aux.spill)[threadIdx.x & 63] = reinterpret_cast<const uint4 *>(sc.objs + i)[threadIdx.x & 63];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            obp = aux.spill;
+        }
+        const ObjRec &ob = *obp;
         const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
         if (kind == KIND_SPHERE) {
             const double len = sphere_len(ob, o, d);
@@ -257,7 +311,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
     }
     if (best.id >= 0 && nsrc == 0) {
         const V3 p = o + d * best.t;  // objects.h:65-66
-        best.n = normalized(p - ld3(objs[best.id].a));
+        best.n = normalized(p - load_centre(objs, n_lds, sc.objs, best.id));
     }
     return best;
 }

@@ -145,6 +145,13 @@ struct BezSlabRec {
 };
 static constexpr int kBezSlabs = 64;
 
+// Top-level objects kept in LDS per workgroup: 768 x 128 B = 96 KiB, which leaves every kernel variant's other LDS (pending-ray
+// levels 38 KiB, node cache 8 KiB, wide-walk stack 32 KiB, Bezier scratch) inside a CU's 160 KiB.  `vector<Object*> objs`
+// (main.cpp:277) has no bound: objects beyond that are read from HBM / L2 -- through the scalar cache in the sphere loop, through a
+// per-wave LDS staging record in the general loop.
+static constexpr int kLdsObjsMax = 768;
+static constexpr int kMaxObjs = 1 << 20;  // sanity limit of cgrt_scene_add_* (CGRT_ERR_LIMIT beyond it)
+
 // Kernel argument block.
 struct DeviceScene {
     const ObjRec *objs;
@@ -162,6 +169,9 @@ struct DeviceScene {
     const BezSlabRec *bez_slabs;  // n_beziers x kBezSlabs
     const double *cover;  // n_cover x (cx, cy, cz, r): spheres that together contain every mesh triangle
     int32_t n_objs, n_trees, n_texs, n_beziers;
+    int32_t n_lds;       // objects 0 .. n_lds-1 are staged in LDS by every workgroup (all of them up to kLdsObjsMax); the rest are
+                         // read from `objs` where the walk needs them (cgrt_scene_walk.hpp)
+    int32_t pad_lds_;
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
     int32_t has_bezier;
     int32_t all_spheres; // fast path selector

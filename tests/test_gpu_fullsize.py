@@ -211,7 +211,7 @@ def test_edge_cases(gpu_ready, orc):
         want = o.trace_grid(cam, 64, 36, 2, depth, 5)
         assert got["nrays"] == want["nrays"] and np.array_equal(got["rgb"], to_acc32(want["acc_sum"], 2)), depth
     sc.close()
-    # the documented limit of 96 top-level objects, mixed materials, ties between coincident spheres
+    # 96 top-level objects (round 2's limit, the whole list in LDS), mixed materials, ties between coincident spheres
     rng = np.random.default_rng(0)
     objs = scenes.wall_spheres()
     while len(objs) < 96:
@@ -226,6 +226,54 @@ def test_edge_cases(gpu_ready, orc):
     want = BackendScene(orc, objs).trace_grid(cam, 160, 120, 2, 5, 9)
     assert got["nrays"] == want["nrays"] and np.array_equal(got["rgb"], to_acc32(want["acc_sum"], 2))
     sc.close()
+
+
+def _many_spheres(n, seed):
+    rng = np.random.default_rng(seed)
+    objs = scenes.wall_spheres()
+    while len(objs) < n:
+        c = (rng.uniform(-17, 17), rng.uniform(-18, 17), rng.uniform(12, 38))
+        refl, transp = [(0, 0), (0, 0), (0.8, 0), (0.8, 0.5)][rng.integers(0, 4)]
+        s = scenes.Sphere(c, rng.uniform(0.3, 1.6), tuple(rng.uniform(0.2, 1, 3)), refl, transp)
+        objs.append(s)
+        if len(objs) < n and rng.random() < 0.05:  # an exact duplicate later in the list: the earlier object wins (main.cpp:57)
+            objs.append(scenes.Sphere(c, s.radius, (1.0, 0.0, 1.0), 0, 0))
+    return objs
+
+
+def test_a_thousand_objects(gpu_ready, orc, monkeypatch):
+    """`vector<Object*> objs` is unbounded (main.cpp:277).  1 000 spheres: 768 of them live in LDS (kLdsObjsMax), the other 232
+    are read through the scalar cache; the oracle's frame, exactly -- mirror, glass and duplicated spheres included, with the
+    duplicates on either side of the LDS boundary.  Then a scene of every object kind with only 7 of its 40 objects resident
+    (CGRT_LDS_OBJS): the general loop's staging record, eye pass and photon pass."""
+    import cgraytracing_amd as cg
+    cam = scenes.cam_dof()
+    objs = _many_spheres(1000, 11)
+    with cg.Scene(objs) as sc:
+        got = sc.trace_grid_host(160, 96, 2, cam, 5, 9)
+    want = BackendScene(orc, objs).trace_grid(cam, 160, 96, 2, 5, 9)
+    assert got["nrays"] == want["nrays"] and np.array_equal(got["nhit"], want["nhit"])
+    assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], 2))
+    # general loop: planes (one bump-mapped), spheres of every material, a glass mesh, an opaque mesh -- 40 objects, 7 resident
+    objs = scenes.planes(scenes.stone_small_texture(True)) + _many_spheres(38, 3)[5:]
+    objs.insert(9, scenes.TriangleMesh.from_triangles(scenes.pyramid_tris(0.6, (-6.0, -13.0, 36.0)), (0.6, 0.7, 0.9), 0.0, 0.0))
+    objs.append(scenes.TriangleMesh.from_triangles(scenes.bunny_tris() * 0.5 + np.tile([6.0, -6.0, 12.0], 3), (1.0, 1.0, 1.0), 0.8, 0.5))
+    assert len(objs) == 40
+    want = BackendScene(orc, objs).trace_grid(cam, 128, 96, 2, 5, 4)
+    wantp = BackendScene(orc, objs).ppm(scenes.cam_pinhole(), 48, 36, 1, 5, nphotons=3000)
+    for resident in ("7", None):
+        if resident:
+            monkeypatch.setenv("CGRT_LDS_OBJS", resident)
+        else:
+            monkeypatch.delenv("CGRT_LDS_OBJS")
+        with cg.Scene(objs) as sc:
+            got = sc.trace_grid_host(128, 96, 2, cam, 5, 4)
+            gotn = sc.trace_grid_host(128, 96, 2, cam, 5, 4, reorder=False)
+            ph = sc.ppm_render(48, 36, 1, scenes.cam_pinhole(), 5, 12345, nphotons=3000)
+        for g in (got, gotn):
+            assert g["nrays"] == want["nrays"] and np.array_equal(g["nhit"], want["nhit"]), resident
+            assert np.array_equal(g["rgb"], to_acc32(want["acc_sum"], 2)), resident
+        assert np.array_equal(ph["image"], wantp["image"]), resident
 
 
 def test_reference_main_configuration_properties(gpu_ready, orc):

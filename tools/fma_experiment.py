@@ -32,7 +32,9 @@ print(json.dumps({"ms": e0.elapsed_time(e1) / 10, "rays": int(cnt[0]) // 10}))
 def run(lib):
     out = tempfile.mktemp(suffix=".npy")
     env = dict(os.environ)
-    if lib: env["CGRT_LIB"] = lib
+    if lib:
+        env["CGRT_LIB"] = lib
+        env["CGRT_DEV_LIBS"] = "1"
     p = subprocess.run([sys.executable, "-c", CHILD, ROOT, out], env=env, capture_output=True, text=True)
     if p.returncode: raise SystemExit(p.stderr)
     info = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
