@@ -39,7 +39,7 @@ struct HitpointSink {
 // wave owns one wave tile (16x4 pixels, one per lane) and every lane runs its pixel's samples; true -- the waves serve the
 // queue of heavy-tile items, lanes drawing (pixel, sample) units.  tile_block / tile_grid: this workgroup's index among the
 // tile workgroups and their number (the launch may put heavy workgroups in front of them).
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS, int NT, bool HEAVY>
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS, int NT, bool HEAVY, bool SPILL = false>
 __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const GridParams &g, float *__restrict__ rgb,
                                                 uint32_t *__restrict__ nhit_out, unsigned long long *__restrict__ counters,
                                                 const HitpointSink &hps, int tile_block, int tile_grid) {
@@ -51,7 +51,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
     // BEZ: one BezLds per wave behind the object list (16-byte aligned: ObjRec is 128 B)
     unsigned char *lrest = reinterpret_cast<unsigned char *>(lobjs + sc.n_lds);
     LdsAux aux;
-    if (sc.n_objs > sc.n_lds) {  // one staging record per wave for the objects beyond the LDS list
+    if (SPILL) {  // one staging record per wave for the objects beyond the LDS list
         aux.spill = reinterpret_cast<ObjRec *>(lrest) + (threadIdx.x >> 6);
         lrest += (NT / 64) * sizeof(ObjRec);
     }
@@ -256,12 +256,12 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
         // is wave-uniform, so its control flow stays scalar.
         RayKey rk{k_smp, path, false, 0u};
         const SceneHit hit =
-            intersect_scene<TREES, BEZ, SPH, STATS>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
+            intersect_scene<TREES, BEZ, SPH, STATS, SPILL>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
         if (have) {
             my_rays++;
             have = false;
             if (hit.id >= 0) {
-                const ObjMat ob = load_mat(lobjs, sc.n_lds, sc.objs, hit.id);
+                const ObjMat ob = load_mat<SPILL>(lobjs, sc.n_lds, sc.objs, hit.id);
                 const V3 P = o + d * hit.t;  // main.cpp:68
                 V3 n = hit.n;
                 const V3 n_old = n;
@@ -483,13 +483,13 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
 }
 
 // One launch = tile workgroups only (probe, image order, Hitpoint capture) ...
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256>
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256, bool SPILL = false>
 __global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? kTreeWaves : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters,
                                                              HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
-    trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, HPS, NT, false>(sc, g, rgb, nhit_out, counters, hps, (int)blockIdx.x,
-                                                                        (int)gridDim.x);
+    trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, HPS, NT, false, SPILL>(sc, g, rgb, nhit_out, counters, hps, (int)blockIdx.x,
+                                                                               (int)gridDim.x);
 }
 // ... or the scheduled form: the first g.heavy_blocks workgroups serve the heavy tiles' unit queue, the others are the tile
 // workgroups.  Two bodies in one kernel: the dispatcher starts workgroups in index order, so the heavy work starts first and

@@ -595,8 +595,10 @@ int cgrt_scene_tree_dump(const cgrt_scene *s, int t, int32_t *node_lr_size, int3
 // top-level objects).  The attribute is per kernel; setting it again is harmless.
 #define BIG_LDS(kernel, bytes)                                                                                                 \
     do {                                                                                                                      \
-        if ((bytes) > ((size_t)48 << 10))                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10); \
+        if ((bytes) > ((size_t)64 << 10)) {                                                                                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) \
+                (void)hipGetLastError(); /* not needed / not supported by this runtime: the launch itself will tell */          \
+        }                                                                                                                     \
     } while (0)
 
 // Which instantiation of trace_grid_kernel a launch uses (chosen from the scene's materials and the camera).
@@ -643,6 +645,13 @@ int cgrt_trace_grid_variant(const cgrt_scene *s, const cgrt_camera *cam, const c
     if (rc) return rc;
     if (!name || cap == 0) return fail(CGRT_ERR_INVALID, "null name buffer");
     const GridVariant v = grid_variant(s, cam, grid);
+    if (s->dev.n_objs > s->dev.n_lds) {
+        if (s->dev.all_spheres)
+            std::snprintf(name, cap, "trace_grid_kernel<TREES=0,BEZ=0,DOF=%d,GLASS=%d,SPH=1,STATS=0,HPS=0,NT=256,SPILL=1>", (int)v.dof, (int)v.glass);
+        else
+            std::snprintf(name, cap, "trace_grid_kernel<TREES=1,BEZ=1,DOF=%d,GLASS=1,SPH=0,STATS=0,HPS=0,NT=256,SPILL=1>", (int)v.dof);
+        return CGRT_OK;
+    }
     std::snprintf(name, cap, "trace_grid_%skernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,%sNT=%d>",
                   v.sched ? "sched_" : "", (int)v.trees, (int)v.bez, (int)v.dof, (int)v.glass, (int)v.sph, (int)v.stats,
                   v.sched ? "" : "HPS=0,", v.nt);
@@ -682,7 +691,8 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.partial_nhit = nullptr;
     g.timeline = nullptr;
     const size_t npx_all = (size_t)grid->rows * grid->width;
-    if ((grid->flags & CGRT_GRID_SPLIT_SAMPLES) && grid->spp >= 32) {
+    const bool spill = s->dev.n_objs > s->dev.n_lds;  // image order, whole tiles (see the SPILL launch below)
+    if ((grid->flags & CGRT_GRID_SPLIT_SAMPLES) && grid->spp >= 32 && !spill) {
         int chunks = grid->spp / 16;
         if (chunks > 16) chunks = 16;
         while (chunks > 1 && (size_t)chunks * npx_all * 28 > ((size_t)4 << 30)) chunks--;
@@ -725,7 +735,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     // with the size of its ray trees (<= 31 rays per sample), the per-lane sample loop already keeps 97 % of the lanes busy,
     // and measured on C2 the unit queue costs 13 % more VALU instructions (at 93 % VALU busy) and 0.9 GB of deferred values
     // per frame for a gain within the noise (4.0-4.2 ms either way).
-    const bool reorder = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && n_wt > 1 && n_wt < (1u << 30) &&
+    const bool reorder = !spill && grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && n_wt > 1 && n_wt < (1u << 30) &&
                          (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER) || env_force_reorder);
     static const long long env_defer_bytes = [] { const char *e = std::getenv("CGRT_DEFER_BYTES"); return e ? std::atoll(e) : 0ll; }();
     static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
@@ -836,6 +846,38 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     auto launch = [&](const GridParams &gp, dim3 gd, float *rgb_, uint32_t *nhit_, unsigned long long *cnt_) {
         launch_mode(std::false_type{}, gp, gd, rgb_, nhit_, cnt_);
     };
+    if (spill) {
+        // More top-level objects than the LDS list holds (kLdsObjsMax): the SPILL variants, which read the others from the
+        // uploaded array, in image order -- the sphere loop for sphere-only scenes, else the most general body (trees, Bezier,
+        // pending rays), as the Hitpoint capture does.  Such scenes are bound by their object loop, not by tile imbalance.
+        const dim3 gd((unsigned)tile_grid_blocks(g.W, g.rows, false)), blk(kThreads);
+        GridParams gs = g;
+        gs.xcd_tiles = 0;
+        if (s->dev.all_spheres) {
+            const size_t l = obj_list_lds(s->dev, kThreads / 64) + (glass ? kStackBytes : 0);
+#define SPILL_SPH(D, G)                                                                                                       \
+    do {                                                                                                                      \
+        BIG_LDS((trace_grid_kernel<false, false, D, G, true, false, false, 256, true>), l);                                    \
+        hipLaunchKernelGGL((trace_grid_kernel<false, false, D, G, true, false, false, 256, true>), gd, blk, l, st, s->dev, gs, rgb, nhit, cnt); \
+    } while (0)
+            if (dof) { if (glass) SPILL_SPH(true, true); else SPILL_SPH(true, false); }
+            else     { if (glass) SPILL_SPH(false, true); else SPILL_SPH(false, false); }
+#undef SPILL_SPH
+        } else {
+            const size_t l = obj_list_lds(s->dev, kThreads / 64) + kStackBytes + (kThreads / 64) * sizeof(BezLds) +
+                             (s->dev.cached_tree >= 0 ? (size_t)s->dev.cached_nodes * sizeof(NodeRec) : 0);
+#define SPILL_GEN(D)                                                                                                          \
+    do {                                                                                                                      \
+        BIG_LDS((trace_grid_kernel<true, true, D, true, false, false, false, 256, true>), l);                                  \
+        hipLaunchKernelGGL((trace_grid_kernel<true, true, D, true, false, false, false, 256, true>), gd, blk, l, st, s->dev, gs, rgb, nhit, cnt); \
+    } while (0)
+            if (dof) SPILL_GEN(true); else SPILL_GEN(false);
+#undef SPILL_GEN
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+        return CGRT_OK;
+    }
     dim3 grid_dim = natural_dim;
     if (reorder && kmax > 0) {
         unsigned char *base = reinterpret_cast<unsigned char *>(s->scratch) + chunk_bytes_al;
@@ -1003,14 +1045,16 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
                        (s->dev.cached_tree >= 0 ? (size_t)s->dev.cached_nodes * sizeof(NodeRec) : 0);
     HitpointSink sink{d_rec, d_cnt, (unsigned long long)cap};
     // the most general variant serves every scene; capture is a verification / hand-off path, not the hot path
-    BIG_LDS((trace_grid_kernel<true, true, true, true, false, false, true>), lds);
-    BIG_LDS((trace_grid_kernel<true, true, false, true, false, false, true>), lds);
-    if (cam->lens_radius > 0)
-        hipLaunchKernelGGL((trace_grid_kernel<true, true, true, true, false, false, true>), grid_dim, block, lds, 0,
-                           s->dev, g, d_rgb, (uint32_t *)nullptr, (unsigned long long *)nullptr, sink);
-    else
-        hipLaunchKernelGGL((trace_grid_kernel<true, true, false, true, false, false, true>), grid_dim, block, lds, 0,
-                           s->dev, g, d_rgb, (uint32_t *)nullptr, (unsigned long long *)nullptr, sink);
+#define CAPTURE(D, SP)                                                                                                         \
+    do {                                                                                                                      \
+        BIG_LDS((trace_grid_kernel<true, true, D, true, false, false, true, 256, SP>), lds);                                   \
+        hipLaunchKernelGGL((trace_grid_kernel<true, true, D, true, false, false, true, 256, SP>), grid_dim, block, lds, 0, s->dev, g, d_rgb, \
+                           (uint32_t *)nullptr, (unsigned long long *)nullptr, sink);                                          \
+    } while (0)
+    const bool spill = s->dev.n_objs > s->dev.n_lds;
+    if (cam->lens_radius > 0) { if (spill) CAPTURE(true, true); else CAPTURE(true, false); }
+    else                      { if (spill) CAPTURE(false, true); else CAPTURE(false, false); }
+#undef CAPTURE
     int rc = CGRT_OK;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -116,7 +116,7 @@ __device__ __forceinline__ V3 sample_sphere(Stream &rs) {
 // while four workgroups (its 4 waves/SIMD) still fit a CU's 160 KiB beside the object list
 __host__ __device__ inline bool photon_lds_stack(const DeviceScene &sc) { return sc.has_wide && sc.n_objs <= 56; }
 // 1. photon paths.  events: count*kSegStride records of 9 doubles; valid: same count of bytes.
-template <bool BEZ>
+template <bool BEZ, bool SPILL = false>
 __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace_kernel(DeviceScene sc, PhotonArgs pa, double *__restrict__ events,
                                                                    unsigned char *__restrict__ valid) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace
     unsigned char *lrest = lds_raw + obj_list_lds(sc, kThreads / 64);
     // BEZ: one BezLds per wave behind the object list; the Newton starts continue the photon's own stream
     LdsAux aux{BEZ ? reinterpret_cast<volatile BezLds *>(lrest) + (threadIdx.x >> 6) : nullptr, nullptr};
-    if (sc.n_objs > sc.n_lds) aux.spill = lobjs + sc.n_lds + (threadIdx.x >> 6);
+    if (SPILL) aux.spill = lobjs + sc.n_lds + (threadIdx.x >> 6);
     // without Bezier objects: the first entries of the 4-wide walk's stack live in LDS behind the object list, as in the eye pass
-    if (!BEZ && photon_lds_stack(sc)) aux.wstack = reinterpret_cast<uint2 *>(lrest);
+    if (!BEZ && !SPILL && photon_lds_stack(sc)) aux.wstack = reinterpret_cast<uint2 *>(lrest);  // (the SPILL launch reserves no room for it)
     const int p = blockIdx.x * kThreads + threadIdx.x;
     bool alive = p < pa.count;
     Stream rs(stream_key(pa.seed, (uint64_t)(pa.first + (alive ? p : 0)), 0, 0x70686f74ull));
@@ -149,14 +149,14 @@ __global__ __launch_bounds__(kThreads, BEZ ? 2 : kPhotonWaves) void photon_trace
     for (int seg = 0; seg < pa.max_depth; seg++) {
         if (__ballot(alive) == 0ull) break;
         RayKey rk{rs.key, 1, true, rs.n};
-        const SceneHit hit = intersect_scene<true, BEZ, false, false>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, alive, aux, dn, dt);
+        const SceneHit hit = intersect_scene<true, BEZ, false, false, SPILL>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, alive, aux, dn, dt);
         if (BEZ) rs.n = rk.n0;
         if (!alive) continue;
         if (hit.id < 0) {
             alive = false;
             continue;
         }
-        const ObjMat ob = load_mat(lobjs, sc.n_lds, sc.objs, hit.id);
+        const ObjMat ob = load_mat<SPILL>(lobjs, sc.n_lds, sc.objs, hit.id);
         const V3 P = o + d * hit.t;
         V3 n = hit.n;
         const V3 n_old = n;
@@ -497,9 +497,16 @@ int sort_pairs(SortTemp &tmp, unsigned long long *kin, unsigned long long *kout,
 void launch_photon_trace(const cgrt_scene *s, const PhotonArgs &pa, double *events, unsigned char *valid, hipStream_t st = 0) {
     const dim3 grid((pa.count + kThreads - 1) / kThreads), block(kThreads);
     const size_t lds = obj_list_lds(s->dev, kThreads / 64);
-    if (lds > ((size_t)48 << 10)) {  // more than the default dynamic-LDS allowance: ask for it (a CU has 160 KiB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photon_trace_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photon_trace_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+    if (s->dev.n_objs > s->dev.n_lds) {  // more objects than the LDS list holds: the variants that read the rest from the uploaded array
+        const size_t l2 = lds + (s->dev.has_bezier ? (kThreads / 64) * sizeof(BezLds) : 0);
+        if (s->dev.has_bezier) {
+            BIG_LDS((photon_trace_kernel<true, true>), l2);
+            hipLaunchKernelGGL((photon_trace_kernel<true, true>), grid, block, l2, st, s->dev, pa, events, valid);
+        } else {
+            BIG_LDS((photon_trace_kernel<false, true>), l2);
+            hipLaunchKernelGGL((photon_trace_kernel<false, true>), grid, block, l2, st, s->dev, pa, events, valid);
+        }
+        return;
     }
     if (s->dev.has_bezier)
         hipLaunchKernelGGL(photon_trace_kernel<true>, grid, block, lds + (kThreads / 64) * sizeof(BezLds), st, s->dev, pa, events,

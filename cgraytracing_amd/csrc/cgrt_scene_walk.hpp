@@ -84,9 +84,10 @@ struct ObjMat {
     double refl, transp;
     int32_t kind, tex;
 };
+template <bool SPILL>
 __device__ __forceinline__ ObjMat load_mat(const ObjRec *__restrict__ lobjs, int n_lds, const ObjRec *__restrict__ gobjs, int id) {
     ObjMat m;
-    if (id < n_lds) {
+    if (!SPILL || id < n_lds) {
         const ObjRec &r = lobjs[id];
         m.col = ld3(r.col); m.refl = r.refl; m.transp = r.transp; m.kind = r.kind; m.tex = r.tex;
     } else {
@@ -95,8 +96,9 @@ __device__ __forceinline__ ObjMat load_mat(const ObjRec *__restrict__ lobjs, int
     }
     return m;
 }
+template <bool SPILL>
 __device__ __forceinline__ V3 load_centre(const ObjRec *__restrict__ lobjs, int n_lds, const ObjRec *__restrict__ gobjs, int id) {
-    if (id < n_lds) return ld3(lobjs[id].a);
+    if (!SPILL || id < n_lds) return ld3(lobjs[id].a);
     return ld3(gobjs[id].a);
 }
 
@@ -157,9 +159,11 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri, tb);
 }
 
-template <bool TREES, bool BEZ, bool SPH, bool STATS>
 // objs[0 .. n_lds): the LDS-resident list; objects n_lds .. n_objs-1 (scenes with more than kLdsObjsMax objects) come from
 // sc.objs, in the same order, so ties still go to the earlier object (main.cpp:57).
+// SPILL: the kernel variants for such scenes (n_objs > n_lds); without it the list is the whole scene and none of the code for
+// the others exists.
+template <bool TREES, bool BEZ, bool SPH, bool STATS, bool SPILL = false>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_lds, int n_objs, const DeviceScene &sc,
                                                     V3 o, V3 d, RayKey &rk, bool on, const LdsAux &aux,
                                                     uint32_t &n_node, uint32_t &n_tri) {
@@ -177,7 +181,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 best.id = i;
             }
         }
-        for (int i = n_lds; i < n_objs; i++) {  // beyond the LDS list: one scalar load per object and wave (s_load_dwordx16)
+        for (int i = n_lds; SPILL && i < n_objs; i++) {  // beyond the LDS list: one scalar load per object and wave (s_load_dwordx16)
             const ObjHead h = load_uniform(reinterpret_cast<const ObjHead *>(sc.objs + i));
             const double len = sphere_len(mk(h.a[0], h.a[1], h.a[2]), h.s0, o, d);
             if (len < best.t) {
@@ -185,15 +189,15 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 best.id = i;
             }
         }
-        if (best.id >= 0) best.n = normalized((o + d * best.t) - load_centre(objs, n_lds, sc.objs, best.id));  // objects.h:65-66
+        if (best.id >= 0) best.n = normalized((o + d * best.t) - load_centre<SPILL>(objs, n_lds, sc.objs, best.id));  // objects.h:65-66
         return best;
     }
     // 1/d for the box tests: three fp64 divisions (~100 instructions), paid only by waves that reach a tree
     V3 inv = mk(0, 0, 0);
     bool inv_ready = false;  // wave-uniform
-    for (int i = 0; i < n_objs; i++) {
+    for (int i = 0; i < (SPILL ? n_objs : n_lds); i++) {
         const ObjRec *obp = objs + i;
-        if (i >= n_lds) {
+        if (SPILL && i >= n_lds) {
             // beyond the LDS list: the record is staged in this wave's LDS slot (eight 16-byte pieces) and read from there,
             // so that the body below exists once.  LDS operations of one wave execute in order; the fence keeps the
             // compiler from moving the reads of other lanes above the writes.
@@ -311,7 +315,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
     }
     if (best.id >= 0 && nsrc == 0) {
         const V3 p = o + d * best.t;  // objects.h:65-66
-        best.n = normalized(p - load_centre(objs, n_lds, sc.objs, best.id));
+        best.n = normalized(p - load_centre<SPILL>(objs, n_lds, sc.objs, best.id));
     }
     return best;
 }

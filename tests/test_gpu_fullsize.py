@@ -261,6 +261,7 @@ def test_a_thousand_objects(gpu_ready, orc, monkeypatch):
     assert len(objs) == 40
     want = BackendScene(orc, objs).trace_grid(cam, 128, 96, 2, 5, 4)
     wantp = BackendScene(orc, objs).ppm(scenes.cam_pinhole(), 48, 36, 1, 5, nphotons=3000)
+    ph_images = []
     for resident in ("7", None):
         if resident:
             monkeypatch.setenv("CGRT_LDS_OBJS", resident)
@@ -273,7 +274,12 @@ def test_a_thousand_objects(gpu_ready, orc, monkeypatch):
         for g in (got, gotn):
             assert g["nrays"] == want["nrays"] and np.array_equal(g["nhit"], want["nhit"]), resident
             assert np.array_equal(g["rgb"], to_acc32(want["acc_sum"], 2)), resident
-        assert np.array_equal(ph["image"], wantp["image"]), resident
+        nd = int((ph["image"] != wantp["image"]).any(axis=2).sum())
+        print("resident=%s: photon image pixels differing from the oracle: %d (max %g), hitpoints %d vs %d" %
+              (resident, nd, np.abs(ph["image"] - wantp["image"]).max(), ph["count"], wantp["n"]))
+        ph_images.append(ph["image"])
+    assert np.array_equal(ph_images[0], ph_images[1])
+    assert nd == 0
 
 
 def test_reference_main_configuration_properties(gpu_ready, orc):
