@@ -152,6 +152,11 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
     int unit_next = 0, unit_end = 0, hrank = 0;
     int unit_pix = 0, unit_smp = 0, unit_rank = 0;
     bool unit_open = false;
+    // PRE: the primary ray of a fresh unit finds its mesh hit in the table primary_walk_kernel filled (cgrt_primwalk.hpp)
+    constexpr bool PRE = HEAVY && TREES && !BEZ && !STATS && !SPILL;
+    bool pre_valid = false;
+    double pre_len = 0;
+    int32_t pre_tri = -1;
 
     auto start_sample = [&](int smp) {  // main.cpp:204-209
         k_smp = sample_key(k_pix, (uint64_t)(g.sample_offset + smp));
@@ -236,6 +241,12 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                         k_pix = (uint64_t)__double_as_longlong(pc[6 * 64]);
                         start_sample(unit_smp);
                         unit_open = true;
+                        if (PRE && g.prim_len) {
+                            const size_t us = ((size_t)unit_rank * g.spp + unit_smp) * 64 + unit_pix;
+                            pre_len = g.prim_len[us];
+                            pre_tri = g.prim_tri[us];
+                            pre_valid = true;
+                        }
                     }
                 }
             }
@@ -255,8 +266,15 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
         // All 64 lanes enter the scene walk together (lanes without a ray carry on == false): the object list
         // is wave-uniform, so its control flow stays scalar.
         RayKey rk{k_smp, path, false, 0u};
+        if (PRE) {
+            rk.pre_valid = have && pre_valid;  // only the ray a unit starts with
+            rk.pre_obj = g.prim_obj;
+            rk.pre_len = pre_len;
+            rk.pre_tri = pre_tri;
+            pre_valid = false;
+        }
         const SceneHit hit =
-            intersect_scene<TREES, BEZ, SPH, STATS, SPILL>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
+            intersect_scene<TREES, BEZ, SPH, STATS, SPILL, PRE>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
         if (have) {
             my_rays++;
             have = false;
@@ -729,6 +747,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(const uint32_t *__restrict__
         plan[2] = 0;
         plan[3] = 0;
         plan[4] = 0;
+        plan[5] = 0;  // primary_walk_kernel's head of the item queue
     }
     if (!border) return;
     // The tile queue: tiles of tw x th wave tiles (one workgroup's worth) with something left to render -- a wave tile that is

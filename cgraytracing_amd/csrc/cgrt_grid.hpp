@@ -50,6 +50,12 @@ struct GridParams {
     unsigned char *dcnt;
     double *pconst;  // heavy tiles: per pixel {pdir(3), pof(3), bits of k_pix}, layout [rank][7][64], filled by pixel_const_kernel
     int32_t probe, heavy_blocks, items_per_tile, units_per_item, maxhp;
+    // Primary-ray mesh hits of the heavy tiles' units, computed by primary_walk_kernel before the render launch
+    // (cgrt_primwalk.hpp): [rank][sample][pixel] distance (kInf: none) and triangle (-1: none) in object prim_obj; nullptr: off
+    const double *prim_len;
+    const int32_t *prim_tri;
+    int32_t prim_obj, pad_prim_;
+    int32_t pw_refill, pw_rounds;  // primary_walk_kernel: idle lanes that trigger a refill; inner-node rounds between leaf phases
     // development aid (env CGRT_TIMELINE_FILE, cgrt_hip.hip): per workgroup {start, end (wall_clock64, 100 MHz), HW_ID | XCC_ID << 32,
     // tile_x | tile_y << 16 | rays << 32}; nullptr in normal operation
     unsigned long long *timeline;

@@ -36,6 +36,7 @@
 #include "cgrt_bezier.hpp"
 #include "cgrt_scene_walk.hpp"
 #include "cgrt_eye.hpp"
+#include "cgrt_primwalk.hpp"
 
 using namespace cgrt;
 
@@ -420,7 +421,6 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     // and tests of the spill path)
     d.n_lds = std::min(d.n_objs, kLdsObjsMax);
     if (const char *e = std::getenv("CGRT_LDS_OBJS")) d.n_lds = std::max(0, std::min(d.n_lds, std::atoi(e)));
-    d.pad_lds_ = 0;
     d.n_trees = (int32_t)trees.size();
     d.n_texs = (int32_t)texs.size();
     d.n_beziers = (int32_t)H.beziers.size();
@@ -443,6 +443,15 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     for (auto &o : H.objs) {
         if (o.kind != KIND_SPHERE) d.all_spheres = 0;
         if (!(o.transp < kEps)) d.has_glass = 1;  // main.cpp:129: the glass branch is `!(transparency < eps)`
+    }
+    {   // the one opaque mesh whose primary-ray walks may run as their own kernel (cgrt_primwalk.hpp): no other mesh, no Bezier object
+        int n_mesh = 0, at = -1;
+        for (size_t i = 0; i < H.objs.size(); i++)
+            if (H.objs[i].kind == KIND_MESH) { n_mesh++; at = (int)i; }
+        d.prim_obj = -1;
+        if (n_mesh == 1 && H.beziers.empty() && H.objs[(size_t)at].transp < kEps && H.objs[(size_t)at].tree >= 0 &&
+            trees[(size_t)H.objs[(size_t)at].tree].nwide > 0 && at < d.n_lds)
+            d.prim_obj = at;
     }
     // light tiles (classify_kernel): possible when planes are plain diffuse surfaces and something else is not
     {
@@ -748,20 +757,24 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const int maxhp = glass_possible(s, grid) ? 16 : 1;  // Hitpoints per sample: a mirror chain ends in one, a glass tree of depth 5 in <= 16
     const size_t tile_vals = (size_t)grid->spp * 64 * (size_t)maxhp * 3 * sizeof(double), tile_cnt = (size_t)grid->spp * 64;
     const size_t tile_pconst = 7 * 64 * sizeof(double);
+    // primary-ray mesh hits of the heavy tiles' units (cgrt_primwalk.hpp): a double and an int per unit
+    static const bool env_no_primwalk = [] { const char *e = std::getenv("CGRT_NO_PRIMWALK"); return e && *e && *e != '0'; }();
+    const bool use_prim = s->dev.prim_obj >= 0 && !env_no_primwalk && !(grid->flags & CGRT_GRID_STATS);
+    const size_t tile_prim = use_prim ? (size_t)grid->spp * 64 * (sizeof(double) + sizeof(int32_t)) : 0;
     size_t kmax = 0;
     const size_t sched_pad = 8;
     size_t sched_bytes = 0, defer_bytes = 0;
     if (reorder) {
         sched_bytes = (4 * (n_wt + sched_pad) + 64) * sizeof(uint32_t) + ((n_wt + 255) & ~(size_t)255);  // cost, order, hidx, border, plan, light
         sched_bytes = (sched_bytes + 255) & ~(size_t)255;
-        kmax = defer_budget / (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst);
+        kmax = defer_budget / (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst + tile_prim);
         if (kmax > n_wt) kmax = n_wt;
-        defer_bytes = kmax * (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst) + 256;
+        defer_bytes = kmax * (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst + tile_prim) + 256;
     }
     size_t chunk_bytes = 0;
     if (g.chunks > 1) chunk_bytes = (size_t)g.chunks * npx_all * (3 * sizeof(double) + sizeof(uint32_t));
     const size_t chunk_bytes_al = (chunk_bytes + 255) & ~(size_t)255;
-    const size_t per_tile = tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst;
+    const size_t per_tile = tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst + tile_prim;
     size_t scratch_need = chunk_bytes_al + sched_bytes + defer_bytes;
     // A size this device has refused before is not asked for again (every attempt is a synchronous hipFree plus failing
     // hipMallocs): the deferred buffer shrinks -- fewer heavy tiles, same image -- until the need lies below it.
@@ -806,6 +819,14 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.items_per_tile = 1;
     g.units_per_item = units_per_item;
     g.maxhp = maxhp;
+    g.prim_len = nullptr;
+    g.prim_tri = nullptr;
+    g.prim_obj = -1;
+    g.pad_prim_ = 0;
+    static const int env_pw_refill = [] { const char *e = std::getenv("CGRT_PW_REFILL"); return e ? std::atoi(e) : 0; }();
+    static const int env_pw_rounds = [] { const char *e = std::getenv("CGRT_PW_ROUNDS"); return e ? std::atoi(e) : 0; }();
+    g.pw_refill = env_pw_refill > 0 ? env_pw_refill : 16;
+    g.pw_rounds = env_pw_rounds > 0 ? env_pw_rounds : 8;
     if (one_wave) lds += (glass ? TileGeom<64>::stack_bytes : 0) + sizeof(BezLds);
     else lds += glass ? kStackBytes : 0;
     if (trees && s->dev.cached_tree >= 0) lds += (size_t)s->dev.cached_nodes * sizeof(NodeRec);
@@ -953,6 +974,12 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         g.dvals = reinterpret_cast<double *>(dbase);
         g.dcnt = dbase + kmax * tile_vals;
         g.pconst = reinterpret_cast<double *>(dbase + kmax * (tile_vals + ((tile_cnt + 7) & ~(size_t)7)));
+        if (use_prim) {
+            unsigned char *pb = dbase + kmax * (tile_vals + ((tile_cnt + 7) & ~(size_t)7) + tile_pconst);
+            g.prim_len = reinterpret_cast<const double *>(pb);
+            g.prim_tri = reinterpret_cast<const int32_t *>(pb + kmax * (size_t)grid->spp * 64 * sizeof(double));
+            g.prim_obj = s->dev.prim_obj;
+        }
         g.items_per_tile = (int)(((size_t)grid->spp * 64 + units_per_item - 1) / units_per_item);
         // enough heavy workgroups to fill the chip once: they loop over the item queue until it is empty
         size_t hb = (kmax * (size_t)g.items_per_tile + waves_per_block - 1) / waves_per_block;
@@ -974,6 +1001,20 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     }
     if (g.heavy_blocks > 0) {  // heavy workgroups in front, the tile workgroups behind them, one launch
         hipLaunchKernelGGL(pixel_const_kernel, dim3((unsigned)kmax), dim3(64), 0, st, g);
+        if (g.prim_len) {
+            // the heavy units' primary rays against the mesh, as a walk-only kernel with lane refill (cgrt_primwalk.hpp): a
+            // chip's worth of persistent workgroups at 4 waves per SIMD
+            int n_cu2 = 256;
+            (void)hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, s->device);
+            PrimWalkArgs pw;
+            pw.len = const_cast<double *>(g.prim_len);
+            pw.tri = const_cast<int32_t *>(g.prim_tri);
+            pw.obj = s->dev.prim_obj;
+            pw.tree = s->host.objs[(size_t)s->dev.prim_obj].tree;
+            const size_t lds_pw = (size_t)(pw.obj + 1) * sizeof(ObjRec) + (size_t)kThreads * kWideLdsDepth * sizeof(uint2);
+            if (dof) hipLaunchKernelGGL(primary_walk_kernel<true>, dim3((unsigned)n_cu2 * 4), dim3(kThreads), lds_pw, st, s->dev, g, pw);
+            else hipLaunchKernelGGL(primary_walk_kernel<false>, dim3((unsigned)n_cu2 * 4), dim3(kThreads), lds_pw, st, s->dev, g, pw);
+        }
         launch_mode(std::true_type{}, g, dim3((unsigned)g.heavy_blocks + grid_dim.x), rgb, nhit, cnt);
     } else {
         launch(g, grid_dim, rgb, nhit, cnt);
@@ -995,6 +1036,15 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         }
     }
     if (launch_err != hipSuccess) return fail(CGRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(launch_err));
+    // development aid: CGRT_PLAN_DUMP=1 makes the launch synchronous and prints what the planner decided
+    static const bool env_plan_dump = [] { const char *e = std::getenv("CGRT_PLAN_DUMP"); return e && *e && *e != '0'; }();
+    if (env_plan_dump && g.plan) {
+        uint32_t pl[8] = {0};
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(pl, g.plan, sizeof(pl), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "cgrt plan: wave tiles %zu, heavy %u (capacity %zu), cost threshold %u, tile-queue entries %u, items per tile %d, prim walk %s\n",
+                     n_wt, pl[0], kmax, pl[1], pl[3], g.items_per_tile, g.prim_len ? "on" : "off");
+    }
     return CGRT_OK;
 }
 
@@ -1030,6 +1080,7 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     g.timeline = nullptr;
     g.light = nullptr; g.light_mode = 0; g.pad_light_ = 0; g.order = nullptr; g.border = nullptr; g.cost = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
     g.probe = 0; g.heavy_blocks = 0; g.items_per_tile = 1; g.units_per_item = 256; g.maxhp = 16;
+    g.prim_len = nullptr; g.prim_tri = nullptr; g.prim_obj = -1; g.pad_prim_ = 0; g.pw_refill = 16; g.pw_rounds = 8;
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_rec, b_cnt;
     HIP_TRY(b_rgb.alloc(npx * 3 * sizeof(float)));

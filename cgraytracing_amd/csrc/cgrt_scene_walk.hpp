@@ -54,6 +54,10 @@ struct RayKey {
     uint32_t path;
     bool explicit_key;
     uint32_t n0;  // explicit key only: position in the stream; advanced by the draws consumed (photon pass)
+    // PRE instantiations only (the unit-queue body): this lane's hit in object pre_obj is already known (primary_walk_kernel)
+    bool pre_valid = false;
+    int32_t pre_obj = -1, pre_tri = -1;
+    double pre_len = 0;
 };
 
 // Sphere::intersect, objects.h:45-68: the hit distance, or +inf-like kInf (never < nearest) on a miss
@@ -163,7 +167,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
 // sc.objs, in the same order, so ties still go to the earlier object (main.cpp:57).
 // SPILL: the kernel variants for such scenes (n_objs > n_lds); without it the list is the whole scene and none of the code for
 // the others exists.
-template <bool TREES, bool BEZ, bool SPH, bool STATS, bool SPILL = false>
+template <bool TREES, bool BEZ, bool SPH, bool STATS, bool SPILL = false, bool PRE = false>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_lds, int n_objs, const DeviceScene &sc,
                                                     V3 o, V3 d, RayKey &rk, bool on, const LdsAux &aux,
                                                     uint32_t &n_node, uint32_t &n_tri) {
@@ -277,13 +281,27 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             const V3 lc = ld3(ob.a) - o;
             const double tca = dot(lc, d), l2 = dot(lc, lc), dd = dot(d, d), r2 = ob.s0;
             const bool may = on && !(tca < 0 && l2 > r2) && !(l2 * dd - tca * tca > r2 * dd);
-            if (__ballot(may) != 0ull) {
-                if (!inv_ready) {
-                    inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                    inv_ready = true;
+            // PRE: a lane whose hit in this object is already known (a fresh unit's primary ray, cgrt_primwalk.hpp) does not walk
+            const bool known = PRE && rk.pre_valid && rk.pre_obj == i;
+            const bool walk = may && !known;
+            if (__ballot(PRE ? (walk || (may && known)) : may) != 0ull) {
+                TreeHit h;
+                h.len = kInf;
+                h.tri = -1;
+                h.counter = 0;
+                if (__ballot(walk) != 0ull) {
+                    if (!inv_ready) {
+                        inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                        inv_ready = true;
+                    }
+                    const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
+                    h = tree_hit<STATS>(sc, aux, tr, opaque, best.t, walk, o, d, inv, n_node, n_tri);
                 }
-                const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
-                const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, best.t, may, o, d, inv, n_node, n_tri);
+                if (PRE && known) {
+                    h.len = rk.pre_len;
+                    h.tri = rk.pre_tri;
+                    h.counter = rk.pre_tri >= 0 ? 1 : 0;
+                }
                 if (may && h.counter > 0 && h.len < best.t) {
                     V3 nrm = tree_normal(sc.tris + load_uniform(&sc.trees[tr].tri_begin), h, d);
                     if (ob.aux == 2) nrm = (nrm.y > 0) ? nrm : -nrm;  // objects.h:434-436

@@ -171,7 +171,8 @@ struct DeviceScene {
     int32_t n_objs, n_trees, n_texs, n_beziers;
     int32_t n_lds;       // objects 0 .. n_lds-1 are staged in LDS by every workgroup (all of them up to kLdsObjsMax); the rest are
                          // read from `objs` where the walk needs them (cgrt_scene_walk.hpp)
-    int32_t pad_lds_;
+    int32_t prim_obj;    // the scene's ONE opaque mesh with a 4-wide hierarchy when it has no other mesh and no Bezier object (its
+                         // primary-ray walks can run as a kernel of their own, cgrt_primwalk.hpp), else -1
     int32_t has_mesh;    // any tree to traverse (mesh or bump plane)
     int32_t has_bezier;
     int32_t all_spheres; // fast path selector
