@@ -1,4 +1,4 @@
-// The primary-ray mesh walk as a kernel of its own (round 3; DESIGN.md section 4.9).  Part of libcgrt.so (cgrt_hip.hip).
+// The primary-ray mesh walk as a kernel of its own (round 3; DESIGN.md section 4.12).  Part of libcgrt.so (cgrt_hip.hip).
 //
 // What was wrong.  Inside a heavy tile (cgrt_eye.hpp, unit-queue body) nearly every ray enters the mesh's hierarchy, but their
 // walks are 3 to 60 node visits long, and a lane whose walk is over waits -- with its whole ray state, shading code and
