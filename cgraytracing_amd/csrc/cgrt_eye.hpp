@@ -39,7 +39,7 @@ struct HitpointSink {
 // wave owns one wave tile (16x4 pixels, one per lane) and every lane runs its pixel's samples; true -- the waves serve the
 // queue of heavy-tile items, lanes drawing (pixel, sample) units.  tile_block / tile_grid: this workgroup's index among the
 // tile workgroups and their number (the launch may put heavy workgroups in front of them).
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS, int NT, bool HEAVY, bool SPILL = false>
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS, int NT, bool HEAVY, bool SPILL = false, bool HFONLY = false>
 __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const GridParams &g, float *__restrict__ rgb,
                                                 uint32_t *__restrict__ nhit_out, unsigned long long *__restrict__ counters,
                                                 const HitpointSink &hps, int tile_block, int tile_grid) {
@@ -274,7 +274,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
             pre_valid = false;
         }
         const SceneHit hit =
-            intersect_scene<TREES, BEZ, SPH, STATS, SPILL, PRE>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
+            intersect_scene<TREES, BEZ, SPH, STATS, SPILL, PRE, HFONLY>(lobjs, sc.n_lds, sc.n_objs, sc, o, d, rk, have, aux, my_nodes, my_tris);
         if (have) {
             my_rays++;
             have = false;
@@ -501,13 +501,13 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
 }
 
 // One launch = tile workgroups only (probe, image order, Hitpoint capture) ...
-template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256, bool SPILL = false>
-__global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? kTreeWaves : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
+template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256, bool SPILL = false, bool HFONLY = false>
+__global__ __launch_bounds__(NT, BEZ ? kBezWaves : ((TREES && !HFONLY) ? kTreeWaves : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters,
                                                              HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
-    trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, HPS, NT, false, SPILL>(sc, g, rgb, nhit_out, counters, hps, (int)blockIdx.x,
-                                                                               (int)gridDim.x);
+    trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, HPS, NT, false, SPILL, HFONLY>(sc, g, rgb, nhit_out, counters, hps, (int)blockIdx.x,
+                                                                                       (int)gridDim.x);
 }
 // ... or the scheduled form: the first g.heavy_blocks workgroups serve the heavy tiles' unit queue, the others are the tile
 // workgroups.  Two bodies in one kernel: the dispatcher starts workgroups in index order, so the heavy work starts first and

@@ -464,6 +464,9 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         }
         d.light_ok = (planes_plain && special && !d.all_spheres) ? 1 : 0;
         d.light_trees = plane_trees ? 1 : 0;  // the light variant then needs the tree / height-field code (not Bezier, not glass)
+        d.light_hf_only = plane_trees ? 1 : 0;
+        for (auto &o : H.objs)
+            if (o.kind == KIND_PLANE && o.tree >= 0 && !(o.transp < kEps && trees[(size_t)o.tree].hfield >= 0)) d.light_hf_only = 0;
         if (d.light_ok && !s->aux_stream) {
             // the light launch yields to the scheduled one: lowest stream priority
             int prio_least = 0, prio_greatest = 0;
@@ -950,8 +953,18 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
         hipLaunchKernelGGL((trace_grid_kernel<T, false, D, false, false, false>), gd_light, dim3(kThreads), lds_light, s->aux_stream, \
                            s->dev, gl, rgb, nhit, cnt);                                                                       \
     } while (0)
-            if (ltrees) { if (dof) LIGHT(true, true); else LIGHT(true, false); }
+#define LIGHT_HF(D)                                                                                                           \
+    do {                                                                                                                      \
+        BIG_LDS((trace_grid_kernel<true, false, D, false, false, false, false, 256, false, true>), lds_hf);                    \
+        hipLaunchKernelGGL((trace_grid_kernel<true, false, D, false, false, false, false, 256, false, true>), gd_light, dim3(kThreads), lds_hf, \
+                           s->aux_stream, s->dev, gl, rgb, nhit, cnt);                                                         \
+    } while (0)
+            const size_t lds_hf = obj_list_lds(s->dev, kThreads / 64);  // no node cache, no walk stack
+            static const bool env_no_hfonly = [] { const char *e = std::getenv("CGRT_NO_HFONLY"); return e && *e && *e != '0'; }();
+            if (ltrees && s->dev.light_hf_only && !env_no_hfonly) { if (dof) LIGHT_HF(true); else LIGHT_HF(false); }
+            else if (ltrees) { if (dof) LIGHT(true, true); else LIGHT(true, false); }
             else        { if (dof) LIGHT(false, true); else LIGHT(false, false); }
+#undef LIGHT_HF
 #undef LIGHT
             HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
         }

@@ -129,7 +129,9 @@ struct LdsAux {
 // and dropped: with sub-pixel triangles the union of 64 rays' leaf sets approaches their sum.
 // `opaque` (wave-uniform): the owning object's transparency is < eps, so the pruned traversal applies with
 // `bound` = nearest hit distance already known for this ray.
-template <bool STATS>
+// HFONLY: the light-tile variant of scenes whose only reachable trees are opaque bump floors walked as grids
+// (DeviceScene::light_hf_only): none of the hierarchy-walk code -- and none of its registers and scratch -- exists in it.
+template <bool STATS, bool HFONLY = false>
 __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux &aux, int tr, bool opaque, double bound,
                                             bool on, V3 o, V3 d, V3 inv, uint32_t &n_node, uint32_t &n_tri) {
     const TreeRec T = load_uniform(sc.trees + tr);
@@ -138,7 +140,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     none.tri = -1;
     none.counter = 0;
     if (!on) return none;
-    if (opaque && T.hfield >= 0) {  // bump floor: walk the grid instead of the tree (same triangles, same test)
+    if (HFONLY || (opaque && T.hfield >= 0)) {  // bump floor: walk the grid instead of the tree (same triangles, same test)
         const HFieldRec H = load_uniform(sc.hfields + T.hfield);
         return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, o, d, inv, bound, n_node, n_tri);
     }
@@ -167,7 +169,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
 // sc.objs, in the same order, so ties still go to the earlier object (main.cpp:57).
 // SPILL: the kernel variants for such scenes (n_objs > n_lds); without it the list is the whole scene and none of the code for
 // the others exists.
-template <bool TREES, bool BEZ, bool SPH, bool STATS, bool SPILL = false, bool PRE = false>
+template <bool TREES, bool BEZ, bool SPH, bool STATS, bool SPILL = false, bool PRE = false, bool HFONLY = false>
 __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ objs, int n_lds, int n_objs, const DeviceScene &sc,
                                                     V3 o, V3 d, RayKey &rk, bool on, const LdsAux &aux,
                                                     uint32_t &n_node, uint32_t &n_tri) {
@@ -258,7 +260,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                     // a bump hit only counts if it is nearer than the plane itself (objects.h:514) and, to matter,
                     // nearer than the nearest object so far
                     const bool opaque = __builtin_amdgcn_readfirstlane((int)(ob.transp < kEps)) != 0;
-                    const TreeHit h = tree_hit<STATS>(sc, aux, tr, opaque, fmin(len, best.t), want, o, d, inv, n_node, n_tri);
+                    const TreeHit h = tree_hit<STATS, HFONLY>(sc, aux, tr, opaque, fmin(len, best.t), want, o, d, inv, n_node, n_tri);
                     if (want && h.counter > 0 && h.len < len && h.len > 0) {
                         len = h.len;
                         nrm = tree_normal(sc.tris + load_uniform(&sc.trees[tr].tri_begin), h, d);
@@ -271,7 +273,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 best.n = nrm;
                 nsrc = 1;
             }
-        } else if (TREES && kind == KIND_MESH) {
+        } else if (TREES && !HFONLY && kind == KIND_MESH) {
             // TriangleMesh::intersect, objects.h:405-455
             const int tr = __builtin_amdgcn_readfirstlane(ob.tree);
             // Early-out without a division: a ray whose LINE misses the sphere around the mesh's vertices (ObjRec.a, s0, with
