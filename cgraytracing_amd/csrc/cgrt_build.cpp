@@ -536,7 +536,19 @@ void HostTree::build_hfield(int nx, int nz, double x0, double z0, double hx, dou
             for (int32_t k = first; k < first + cnt; k++) leaf_of[(size_t)k] = first;
         }
     hcells.resize((size_t)nx * nz);
+    hcell_y.resize((size_t)nx * nz);
     double ylo = kInf, yhi = -kInf;
+    for (size_t c = 0; c < hcells.size(); c++) {
+        double clo = kInf, chi = -kInf;
+        for (int q = 0; q < 2; q++)
+            for (int v = 0; v < 3; v++) {
+                const double y = tri9[9 * (2 * c + q) + 3 * v + 1];
+                clo = std::min(clo, y);
+                chi = std::max(chi, y);
+            }
+        hcell_y[c].lo = round_down(clo);
+        hcell_y[c].hi = round_up(chi);
+    }
     for (size_t c = 0; c < hcells.size(); c++)
         for (int q = 0; q < 2; q++) {
             const int32_t k = pos[2 * c + q];
@@ -553,6 +565,7 @@ void HostTree::build_hfield(int nx, int nz, double x0, double z0, double hx, dou
     hfield.nx = nx; hfield.nz = nz;
     hfield.x0 = x0; hfield.z0 = z0;
     hfield.hx = hx; hfield.hz = hz;
+    hfield.ihx = 1.0 / hx; hfield.ihz = 1.0 / hz;
     hfield.ylo = ylo; hfield.yhi = yhi;
     is_hfield = true;
 }
@@ -678,6 +691,8 @@ int HostScene::add_plane(const double p[3], const double n[3], const double sc[3
             tree.hfield.z0 = tx.p[2];
             tree.hfield.hx = tx.lenx * step / C;
             tree.hfield.hz = tx.leny * step / R;
+            tree.hfield.ihx = 1.0 / tree.hfield.hx;
+            tree.hfield.ihz = 1.0 / tree.hfield.hz;
             trees.push_back(std::move(tree));
             o.tree = (int)trees.size() - 1;
             objs.push_back(o);

@@ -39,6 +39,7 @@ struct HostTree {
     bool is_hfield = false;
     HFieldRec hfield{};
     std::vector<HCellRec> hcells;
+    std::vector<HCellY> hcell_y;  // per cell: its vertices' height range, rounded outward
     void build(bool opaque = false, bool with_bvh = true);
     void build_hfield(int nx, int nz, double x0, double z0, double hx, double hz);
     // Row f3 (cgrt_devbuild.hpp): an opaque owner's structure is built on the device at commit; nothing above is filled on the

@@ -55,6 +55,7 @@ struct BumpArgs {
     double *ys;  // (nz + 1) x (nx + 1) vertex heights (plane y included)
     unsigned long long *minmax;  // [0] = key of the lowest, [1] = of the highest vertex
     HCellRec *cells;
+    HCellY *celly;
     TriRec *tris;
 };
 
@@ -100,6 +101,10 @@ __global__ void bump_cell_kernel(BumpArgs a) {
     cell.leaf[0] = 0;
     cell.leaf[1] = 0;
     a.cells[c] = cell;
+    HCellY cy;
+    cy.lo = f_down(fmin(fmin(ya, yb), fmin(yc, yd)));
+    cy.hi = f_up(fmax(fmax(ya, yb), fmax(yc, yd)));
+    a.celly[c] = cy;
     a.tris[2 * c] = cell.t[0];
     a.tris[2 * c + 1] = cell.t[1];
 }
@@ -429,7 +434,7 @@ struct BumpResult {
 };
 // texels: device pointer to this texture's bytes; cells / tris: where the records go (device)
 static int build_bump_floor(const uint8_t *texels, int R, int C, const double p[3], double lenx, double leny, double plane_y,
-                            HCellRec *cells, TriRec *tris, BumpResult &out) {
+                            HCellRec *cells, HCellY *celly, TriRec *tris, BumpResult &out) {
     BumpArgs a;
     a.texels = texels;
     a.R = R;
@@ -442,6 +447,7 @@ static int build_bump_floor(const uint8_t *texels, int R, int C, const double p[
     a.nx = C / 3 - 1;
     a.nz = R / 3 - 1;
     a.cells = cells;
+    a.celly = celly;
     a.tris = tris;
     const int nv = (a.nx + 1) * (a.nz + 1), nc = a.nx * a.nz;
     DevBuf ys, mm;

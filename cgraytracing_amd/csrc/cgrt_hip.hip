@@ -247,6 +247,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
     std::vector<TreeRec> trees;
     std::vector<HFieldRec> hfields;
     std::vector<HCellRec> hcells;
+    std::vector<HCellY> hcell_y;
     std::vector<OTriRec> otris;
     std::vector<NodeRec> tboxes;
     std::vector<WideNodeRec> wnodes;
@@ -284,6 +285,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
             tr.hfield = (int32_t)hfields.size();
             hfields.push_back(hf);
             hcells.insert(hcells.end(), t.hcells.begin(), t.hcells.end());
+            hcell_y.insert(hcell_y.end(), t.hcell_y.begin(), t.hcell_y.end());
         }
         tr.tbox_begin = (int64_t)tboxes.size();
         tr.wnode_begin = (int64_t)wnodes.size();
@@ -357,6 +359,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         if ((rc = upload(s, tris, &d.tris, dev_tris))) return rc;
         if ((rc = upload(s, texels, &d.texels))) return rc;
         if ((rc = upload(s, hcells, &d.hcells, dev_hcells))) return rc;
+        if ((rc = upload(s, hcell_y, &d.hcell_y, dev_hcells))) return rc;
         if ((rc = upload(s, otris, &d.otris, dev_otris))) return rc;
         if ((rc = upload(s, tboxes, &d.tboxes))) return rc;
         if ((rc = upload(s, wnodes, &d.wnodes, dev_wnodes))) return rc;
@@ -371,6 +374,7 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
                     devbuild::BumpResult br;
                     if ((rc = devbuild::build_bump_floor(d.texels + texs[(size_t)t.dev_tex].texel_begin, tx.rows, tx.cols, tx.p, tx.lenx,
                                                          tx.leny, t.dev_plane_y, const_cast<HCellRec *>(d.hcells) + hf.cell_begin,
+                                                         const_cast<HCellY *>(d.hcell_y) + hf.cell_begin,
                                                          const_cast<TriRec *>(d.tris) + tr.tri_begin, br)))
                         return rc;
                     hf.ylo = br.ylo;

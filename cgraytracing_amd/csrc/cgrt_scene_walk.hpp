@@ -142,7 +142,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     if (!on) return none;
     if (HFONLY || (opaque && T.hfield >= 0)) {  // bump floor: walk the grid instead of the tree (same triangles, same test)
         const HFieldRec H = load_uniform(sc.hfields + T.hfield);
-        return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, o, d, inv, bound, n_node, n_tri);
+        return hfield_intersect<STATS>(H, sc.hcells + H.cell_begin, sc.hcell_y + H.cell_begin, o, d, inv, bound, n_node, n_tri);
     }
     const bool cached = aux.lnodes != nullptr && tr == sc.cached_tree;
     const Ray32 r32 = make_ray32(o, inv, T.bmax);

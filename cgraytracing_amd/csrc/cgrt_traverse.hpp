@@ -343,7 +343,8 @@ __device__ __forceinline__ TreeHit tree_intersect_wide(const WideNodeRec *__rest
 static constexpr double kHfPad = 1e-9;
 
 template <bool STATS>
-__device__ __forceinline__ TreeHit hfield_intersect(const HFieldRec &H, const HCellRec *__restrict__ cells, V3 o, V3 d,
+__device__ __forceinline__ TreeHit hfield_intersect(const HFieldRec &H, const HCellRec *__restrict__ cells,
+                                                    const HCellY *__restrict__ celly, V3 o, V3 d,
                                                     V3 inv, double bound, uint32_t &n_node, uint32_t &n_tri) {
     TreeHit r;
     r.len = kInf;
@@ -372,7 +373,7 @@ __device__ __forceinline__ TreeHit hfield_intersect(const HFieldRec &H, const HC
     const double om = xmaj ? o.z : o.x, dm = xmaj ? d.z : d.x;
     const double M0 = xmaj ? H.x0 : H.z0, hM = xmaj ? H.hx : H.hz, m0 = xmaj ? H.z0 : H.x0, hm = xmaj ? H.hz : H.hx;
     const int nM = xmaj ? H.nx : H.nz, nm = xmaj ? H.nz : H.nx;
-    const double ihM = 1.0 / hM, ihm = 1.0 / hm;
+    const double ihM = xmaj ? H.ihx : H.ihz, ihm = xmaj ? H.ihz : H.ihx;  // = 1.0 / hM, 1.0 / hm (computed once, at commit)
     const double Ma = oM + dM * ta, Mb = oM + dM * tb;
     int j0 = (int)floor((fmin(Ma, Mb) - kHfPad - M0) * ihM), j1 = (int)floor((fmax(Ma, Mb) + kHfPad - M0) * ihM);
     j0 = j0 < 0 ? 0 : j0;
@@ -394,9 +395,18 @@ __device__ __forceinline__ TreeHit hfield_intersect(const HFieldRec &H, const HC
         int i0 = (int)floor((fmin(ma, mb) - kHfPad - m0) * ihm), i1 = (int)floor((fmax(ma, mb) + kHfPad - m0) * ihm);
         i0 = i0 < 0 ? 0 : i0;
         i1 = i1 > nm - 1 ? nm - 1 : i1;
+        // heights the ray passes through while it is over this column (a hit point lies over its cell, hence within the
+        // column's parameter range [s0, s1], and y is linear in the parameter)
+        const double ya = o.y + d.y * s0, yb = o.y + d.y * s1;
+        const double ymin = fmin(ya, yb) - kHfPad, ymax = fmax(ya, yb) + kHfPad;
         for (int i = i0; i <= i1; i++) {
+            const size_t ci = xmaj ? (size_t)i * H.nx + j : (size_t)j * H.nx + i;
+            // a cell whose four vertices all lie below or all above that range cannot be hit: 8 bytes decide, the 160-byte
+            // record and the two triangle tests are skipped (the stored range is rounded outward)
+            const HCellY cy = celly[ci];
+            if (ymin > (double)cy.hi || ymax < (double)cy.lo) continue;
             if (STATS) n_node++;
-            const HCellRec *cell = cells + (xmaj ? (size_t)i * H.nx + j : (size_t)j * H.nx + i);
+            const HCellRec *cell = cells + ci;
             const int4 ids = *reinterpret_cast<const int4 *>(cell->k);  // k0 k1 leaf0 leaf1
 #pragma unroll
             for (int q = 0; q < 2; q++) {

@@ -112,11 +112,17 @@ struct HCellRec {
 };
 static_assert(sizeof(HCellRec) == 160, "HCellRec layout");
 struct HFieldRec {
-    int64_t cell_begin;  // into hcells[]: cell (i, j) at cell_begin + i * nx + j
+    int64_t cell_begin;  // into hcells[] and hcell_y[]: cell (i, j) at cell_begin + i * nx + j
     int32_t nx, nz;      // cells along x (cols/3 - 1) and z (rows/3 - 1)
     double x0, z0;       // texture position (vertex (0,0))
     double hx, hz;       // cell pitch: lenx*3/cols, leny*3/rows
     double ylo, yhi;     // range of vertex heights (plane y included)
+    double ihx, ihz;     // 1.0 / hx, 1.0 / hz (the same IEEE quotients the walk used to compute per ray)
+};
+// Heights of a cell's four vertices, rounded outward to fp32: a ray that stays above or below them over the cell's column cannot
+// hit its triangles (hfield_intersect's cull; 8 bytes instead of the 160-byte cell record for the cells a ray merely flies over)
+struct HCellY {
+    float lo, hi;
 };
 
 struct TexRec {
@@ -163,6 +169,7 @@ struct DeviceScene {
     const BezierRec *beziers;
     const HFieldRec *hfields;
     const HCellRec *hcells;
+    const HCellY *hcell_y;  // parallel to hcells
     const OTriRec *otris;
     const NodeRec *tboxes;
     const WideNodeRec *wnodes;
