@@ -133,6 +133,55 @@ def test_texture_color_three_orientations_vs_reference_golden(gpu_ready):
         assert np.array_equal(s3.surface_colors(0, P), g["floor_col"])
 
 
+@pytest.mark.parametrize("transp", [0.0, 0.5], ids=["opaque_wide_walk", "glass_leaf_walk"])
+def test_single_precision_box_tests_are_conservative(gpu_ready, orc, transp):
+    """the walks test boxes in fp32 against per-ray grown boxes, which must accept every box the ray
+    really touches whatever the magnitudes involved.  Meshes far from the origin (coordinates up to 3e4, where an fp32 ulp is
+    2e-3 -- larger than many triangles' boxes are thick), rays from far away (1e6), rays with one or two direction components
+    exactly zero, rays that start inside the mesh or on a box face, grazing rays: hit flag, distance and normal must be the
+    oracle's, bit for bit, for an opaque owner (4-wide pruned walk) and a transparent one (leaf scan with per-triangle boxes)."""
+    import cgraytracing_amd as cg
+    rng = np.random.default_rng(77)
+    for offset, scale in [((0.0, -5.0, 30.0), 1.0), ((1.0e4, -2.0e4, 3.0e4), 1.0), ((-3.0e4, 7.0, 11.0), 0.05), ((5.0, 5.0, 5.0), 300.0)]:
+        off = np.asarray(offset)
+        tris = (scenes.procedural_mesh(24, 12, (0.0, 0.0, 0.0), 8.0, seed=9) * scale + np.tile(off, 3)).reshape(-1, 9)
+        objs = [scenes.TriangleMesh.from_triangles(tris, (0.6, 0.7, 0.9), 0.8 if transp else 0.0, transp)]
+        P = tris.reshape(-1, 3, 3)
+        lo, hi = P.min((0, 1)), P.max((0, 1))
+        n = 4000
+        tgt = P[rng.integers(0, len(P), n)].mean(1) + rng.normal(size=(n, 3)) * 0.3 * scale   # near the surface
+        far = rng.choice([12.0 * scale, 300.0 * scale, 1.0e6], n)[:, None]
+        dirs = rng.normal(size=(n, 3))
+        dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+        org = tgt - dirs * far
+        # axis-parallel rays (one or two components exactly zero), aimed at vertices' coordinates
+        k = n // 4
+        ax = rng.integers(0, 3, k)
+        dirs[:k] = 0.0
+        dirs[np.arange(k), ax] = rng.choice([-1.0, 1.0], k)
+        mixed = rng.random(k) < 0.5
+        dirs[:k][mixed, (ax[mixed] + 1) % 3] = rng.choice([-1.0, 1.0], mixed.sum()) * rng.uniform(0.1, 1, mixed.sum())
+        dirs[:k] /= np.linalg.norm(dirs[:k], axis=1)[:, None]
+        org[:k] = tgt[:k] - dirs[:k] * far[:k]
+        # rays that start inside the mesh's box, some exactly on a face of it
+        inside = rng.uniform(lo, hi, (k, 3))
+        face = rng.random(k) < 0.3
+        inside[face, 0] = lo[0]
+        org[k:2 * k] = inside
+        hw, lw, nw = BackendScene(orc, objs).intersect_batch(0, org, dirs)
+        with cg.Scene(objs) as sc:
+            hg, lg, ng = sc.intersect_rays(0, org, dirs)
+        assert hw.sum() > n // 10
+        assert np.array_equal(hg, hw), (offset, int((hg != hw).sum()))
+        m = hw == 1
+        assert np.array_equal(lg[m], lw[m]), offset
+        if transp:
+            assert np.array_equal(ng[m], nw[m]), offset
+        else:  # an opaque owner's normal is defined up to the sign trace() gives it (main.cpp:73-76; PRUNE in cgrt_traverse.hpp)
+            flip = lambda nv, dv: np.where(((nv * dv).sum(1) > 0)[:, None], -nv, nv)
+            assert np.array_equal(flip(ng[m], dirs[m]), flip(nw[m], dirs[m])), offset
+
+
 def test_tangent_rays_on_opaque_mesh(gpu_ready, orc):
     """The documented exception of the pruned traversal (cgrt_traverse.hpp, PRUNE): for an OPAQUE mesh the device
     drops the improvement counter, which only sets the SIGN of the returned normal; trace() re-orients the normal
