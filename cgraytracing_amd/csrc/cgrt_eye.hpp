@@ -234,6 +234,10 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                     j = wy * kWaveTileH + (unit_pix >> 4);
                     h = global_row(g, j);
                     live = (w < g.W) && (j < g.rows) && (h < g.H);
+                    // PRE: a unit primary_walk_kernel has already completed (its nearest object was diffuse) is not opened
+                    if (PRE && live && g.prim_len && g.prim_done &&
+                        g.dcnt[((size_t)unit_rank * g.spp + unit_smp) * 64 + unit_pix] != 255)
+                        live = false;
                     if (live) {
                         const double *pc = g.pconst + (size_t)unit_rank * (7 * 64) + unit_pix;
                         pdir = mk(pc[0 * 64], pc[1 * 64], pc[2 * 64]);

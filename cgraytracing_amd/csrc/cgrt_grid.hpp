@@ -54,7 +54,8 @@ struct GridParams {
     // (cgrt_primwalk.hpp): [rank][sample][pixel] distance (kInf: none) and triangle (-1: none) in object prim_obj; nullptr: off
     const double *prim_len;
     const int32_t *prim_tri;
-    int32_t prim_obj, pad_prim_;
+    int32_t prim_obj;
+    int32_t prim_done;  // primary_walk_kernel also completes units (dcnt != 255: done there, the unit-queue body skips them)
     int32_t pw_refill, pw_rounds;  // primary_walk_kernel: idle lanes that trigger a refill; inner-node rounds between leaf phases
     // development aid (env CGRT_TIMELINE_FILE, cgrt_hip.hip): per workgroup {start, end (wall_clock64, 100 MHz), HW_ID | XCC_ID << 32,
     // tile_x | tile_y << 16 | rays << 32}; nullptr in normal operation

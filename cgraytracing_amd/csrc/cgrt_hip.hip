@@ -456,6 +456,9 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         if (n_mesh == 1 && H.beziers.empty() && H.objs[(size_t)at].transp < kEps && H.objs[(size_t)at].tree >= 0 &&
             trees[(size_t)H.objs[(size_t)at].tree].nwide > 0 && at < d.n_lds)
             d.prim_obj = at;
+        d.prim_finish = d.prim_obj >= 0 ? 1 : 0;
+        for (auto &o : H.objs)
+            if (o.kind == KIND_PLANE && o.tree >= 0) d.prim_finish = 0;
     }
     // light tiles (classify_kernel): possible when planes are plain diffuse surfaces and something else is not
     {
@@ -829,7 +832,7 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     g.prim_len = nullptr;
     g.prim_tri = nullptr;
     g.prim_obj = -1;
-    g.pad_prim_ = 0;
+    g.prim_done = 0;
     static const int env_pw_refill = [] { const char *e = std::getenv("CGRT_PW_REFILL"); return e ? std::atoi(e) : 0; }();
     static const int env_pw_rounds = [] { const char *e = std::getenv("CGRT_PW_ROUNDS"); return e ? std::atoi(e) : 0; }();
     g.pw_refill = env_pw_refill > 0 ? env_pw_refill : 16;
@@ -996,6 +999,8 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
             g.prim_len = reinterpret_cast<const double *>(pb);
             g.prim_tri = reinterpret_cast<const int32_t *>(pb + kmax * (size_t)grid->spp * 64 * sizeof(double));
             g.prim_obj = s->dev.prim_obj;
+            static const bool env_no_finish = [] { const char *e = std::getenv("CGRT_PW_NO_FINISH"); return e && *e && *e != '0'; }();
+            g.prim_done = (s->dev.prim_finish && !env_no_finish) ? 1 : 0;
         }
         g.items_per_tile = (int)(((size_t)grid->spp * 64 + units_per_item - 1) / units_per_item);
         // enough heavy workgroups to fill the chip once: they loop over the item queue until it is empty
@@ -1028,7 +1033,10 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
             pw.tri = const_cast<int32_t *>(g.prim_tri);
             pw.obj = s->dev.prim_obj;
             pw.tree = s->host.objs[(size_t)s->dev.prim_obj].tree;
-            const size_t lds_pw = (size_t)(pw.obj + 1) * sizeof(ObjRec) + (size_t)kThreads * kWideLdsDepth * sizeof(uint2);
+            pw.finish = g.prim_done;
+            pw.pad_ = 0;
+            pw.counters = cnt;
+            const size_t lds_pw = (size_t)(pw.finish ? s->dev.n_objs : pw.obj + 1) * sizeof(ObjRec) + (size_t)kThreads * kWideLdsDepth * sizeof(uint2);
             if (dof) hipLaunchKernelGGL(primary_walk_kernel<true>, dim3((unsigned)n_cu2 * 4), dim3(kThreads), lds_pw, st, s->dev, g, pw);
             else hipLaunchKernelGGL(primary_walk_kernel<false>, dim3((unsigned)n_cu2 * 4), dim3(kThreads), lds_pw, st, s->dev, g, pw);
         }
@@ -1097,7 +1105,7 @@ static int hitpoints_device(const cgrt_scene *s, const cgrt_camera *cam, const c
     g.timeline = nullptr;
     g.light = nullptr; g.light_mode = 0; g.pad_light_ = 0; g.order = nullptr; g.border = nullptr; g.cost = nullptr; g.hidx = nullptr; g.plan = nullptr; g.dvals = nullptr; g.dcnt = nullptr; g.pconst = nullptr;
     g.probe = 0; g.heavy_blocks = 0; g.items_per_tile = 1; g.units_per_item = 256; g.maxhp = 16;
-    g.prim_len = nullptr; g.prim_tri = nullptr; g.prim_obj = -1; g.pad_prim_ = 0; g.pw_refill = 16; g.pw_rounds = 8;
+    g.prim_len = nullptr; g.prim_tri = nullptr; g.prim_obj = -1; g.prim_done = 0; g.pw_refill = 16; g.pw_rounds = 8;
     const size_t npx = (size_t)grid->rows * grid->width;
     DevBuf b_rgb, b_rec, b_cnt;
     HIP_TRY(b_rgb.alloc(npx * 3 * sizeof(float)));

@@ -16,6 +16,14 @@
 // nearest hit does not depend on the order in which leaves are visited nor on the pruning bound, as long as that bound is not
 // below the hit finally accepted: here the walk starts unbounded (the scene walk compares the hit with the other objects'
 // as always).
+//
+// Finishing units here (pw.finish, scenes whose planes carry no bump tree).  When a unit's walk is over, the rest of its primary
+// ray's scene walk is a handful of sphere / plane tests; if the nearest object is DIFFUSE the ray tree ends there with one
+// Hitpoint whose value is the surface colour (adj = (1,1,1), main.cpp:85-100) -- the unit is complete: its value is parked
+// (dvals, dcnt = 1, or dcnt = 0 for a ray that hits nothing) and the unit-queue body skips it.  Only units whose nearest object
+// reflects or refracts are left to that body (dcnt = 255 and the mesh hit in the table).  On C4 every heavy unit completes here,
+// and the scheduled kernel -- which would generate the ray a second time, walk the planes, merge and park -- has nothing left
+// to do for them.  The object loop is intersect_scene's: objects in `objs` order, strict <, the mesh at its own position.
 #ifndef CGRT_PRIMWALK_HPP
 #define CGRT_PRIMWALK_HPP
 #include "cgrt_eye.hpp"
@@ -24,17 +32,21 @@ struct PrimWalkArgs {
     double *len;        // [heavy rank][sample][pixel]: distance of the primary ray's nearest hit in the mesh, kInf if none
     int32_t *tri;       //   ... its triangle (leaf-order index, TreeHit::tri), -1 if none
     int32_t obj, tree;  // the mesh: index in objs, tree index
+    int32_t finish;     // complete units whose nearest object is diffuse here (see above); 0: fill the table only
+    int32_t pad_;
+    unsigned long long *counters;  // finish: rays / Hitpoints of the units completed here (CGRT_CNT_*)
 };
 
 template <bool DOF>
 __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene sc, GridParams g, PrimWalkArgs pw) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw);
-    uint2 *lstack = reinterpret_cast<uint2 *>(lobjs + pw.obj + 1);  // [entry][thread], kWideLdsDepth entries; deeper ones in scratch
-    {   // only the objects up to and including the mesh are needed
+    const int n_stage = pw.finish ? sc.n_objs : pw.obj + 1;  // the mesh's record; all of them when units are finished here
+    uint2 *lstack = reinterpret_cast<uint2 *>(lobjs + n_stage);  // [entry][thread], kWideLdsDepth entries; deeper ones in scratch
+    {
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.objs);
         uint4 *dst = reinterpret_cast<uint4 *>(lobjs);
-        const int n16 = (pw.obj + 1) * (int)(sizeof(ObjRec) / 16);
+        const int n16 = n_stage * (int)(sizeof(ObjRec) / 16);
         for (int k = threadIdx.x; k < n16; k += kThreads) dst[k] = src[k];
     }
     __syncthreads();
@@ -55,7 +67,9 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
     int unit_next = 0, unit_end = 0, hrank = 0;
 
     // the lane's walk
-    bool active = false;
+    bool active = false, pending = false;  // pending: the walk is over (or was not needed), the unit awaits its finish
+    uint32_t my_rays = 0, my_hits = 0;
+    int unit_rank_l = 0, unit_smp_l = 0, unit_pix_l = 0;
     size_t slot = 0;
     V3 o = camorg, d = mk(0, 0, 1);
     Ray32 r32 = make_ray32(o, mk(1, 1, 1), 0.f);
@@ -80,10 +94,68 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
     };
 
     while (true) {
-        // ---- (1) refill: idle lanes draw units once a quarter of the wave is idle (or nothing is walking) ----
-        const unsigned long long idle = __ballot(!active);
+        // ---- (1) refill: once a quarter of the wave is not walking (or nothing is), the lanes whose walk is over finish their
+        // unit (together), then every lane that is not walking draws a new unit ----
+        const unsigned long long notwalking = __ballot(!active);
         const bool fresh_left = !(queue_empty && unit_next >= unit_end);
-        if (idle != 0ull && fresh_left && (__popcll(idle) >= g.pw_refill || idle == ~0ull)) {
+        const bool any_pending = __ballot(pending) != 0ull;
+        if (notwalking != 0ull && (fresh_left || any_pending) && (__popcll(notwalking) >= g.pw_refill || notwalking == ~0ull)) {
+            if (any_pending) {
+                // the rest of the scene walk (main.cpp:55-63): every object in order, the mesh's hit at the mesh's position
+                double bt = kInf;
+                int bid = -1;
+                for (int i = 0; i < sc.n_objs; i++) {
+                    const ObjRec &ob = lobjs[i];
+                    const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
+                    double len = kInf;
+                    if (i == pw.obj) {
+                        if (best_tri >= 0) len = best_len;
+                    } else if (kind == KIND_SPHERE) {
+                        len = sphere_len(ob, o, d);
+                    } else if (kind == KIND_PLANE) {
+                        const double l = plane_len(ob, ld3(ob.b), o, d);
+                        if (l > 0) len = l;  // (no plane of such a scene carries a bump tree)
+                    }
+                    if (len < bt) {
+                        bt = len;
+                        bid = i;
+                    }
+                }
+                if (pending) {
+                    const size_t us = ((size_t)unit_rank_l * g.spp + unit_smp_l) * 64 + unit_pix_l;
+                    bool complete = true;
+                    unsigned char cnt = 0;
+                    if (bid >= 0) {
+                        const ObjRec &ob = lobjs[bid];
+                        if (ob.refl < kEps && ob.transp < kEps) {  // diffuse: Hitpoint{f * adj}, adj = (1,1,1)
+                            V3 f = ld3(ob.col);
+                            if (ob.kind == KIND_PLANE && ob.tex >= 0) {
+                                V3 c;
+                                if (texture_color(sc.texs[ob.tex], sc.texels, o + d * bt, c)) f = c;
+                            }
+                            const V3 hf = mulv(f, mk(1, 1, 1));
+                            double *q = g.dvals + ((((size_t)unit_rank_l * g.spp + unit_smp_l) * g.maxhp + 0) * 64 + unit_pix_l) * 3;
+                            q[0] = hf.x;
+                            q[1] = hf.y;
+                            q[2] = hf.z;
+                            cnt = 1;
+                            my_hits++;
+                        } else {
+                            complete = false;  // a mirror or glass object: the unit-queue body takes it from here
+                        }
+                    }
+                    if (complete) {
+                        g.dcnt[us] = cnt;
+                        my_rays++;
+                    } else {
+                        g.dcnt[us] = 255;
+                        pw.len[us] = best_len;
+                        pw.tri[us] = best_tri;
+                    }
+                    pending = false;
+                }
+            }
+            const unsigned long long idle = __ballot(!active);
             if (unit_next >= unit_end && !queue_empty) {
                 const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)item_ahead);
                 if (lane == 0) item_ahead = atomicAdd(&g.plan[5], 1u);
@@ -106,6 +178,9 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
                 const int j = (int)(wt / (uint32_t)wtiles_x) * kWaveTileH + (unit_pix >> 4);
                 const int h = global_row(g, j);
                 slot = ((size_t)hrank * g.spp + unit_smp) * 64 + unit_pix;
+                unit_rank_l = hrank;
+                unit_smp_l = unit_smp;
+                unit_pix_l = unit_pix;
                 if (!((w < g.W) && (j < g.rows) && (h < g.H))) {
                     fresh = false;  // a pixel outside the image: the unit-queue body never opens it
                 } else {
@@ -148,6 +223,10 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
                     sp = 0;
                     nxt = ~0;  // the root
                     active = true;
+                } else if (pw.finish) {
+                    best_len = kInf;
+                    best_tri = -1;
+                    pending = true;  // no walk needed: finished with the next batch
                 } else {
                     pw.len[slot] = kInf;
                     pw.tri[slot] = -1;
@@ -155,7 +234,7 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
             }
         }
         if (__ballot(active) == 0ull) {
-            if (queue_empty && unit_next >= unit_end) break;
+            if (queue_empty && unit_next >= unit_end && __ballot(pending) == 0ull) break;
             continue;
         }
         // ---- (2) a few rounds of inner-node steps: the lanes that stand on an inner node ----
@@ -229,9 +308,24 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
         }
         // ---- (4) walks that are over ----
         if (active && nxt == kWideNone) {
-            pw.len[slot] = best_len;
-            pw.tri[slot] = best_tri;
             active = false;
+            if (pw.finish) {
+                pending = true;
+            } else {
+                pw.len[slot] = best_len;
+                pw.tri[slot] = best_tri;
+            }
+        }
+    }
+    if (pw.finish && pw.counters) {  // the units completed here: one ray each, one Hitpoint where something diffuse was hit
+        unsigned long long r = my_rays, hh = my_hits;
+        for (int off = 32; off > 0; off >>= 1) {
+            r += __shfl_xor(r, off);
+            hh += __shfl_xor(hh, off);
+        }
+        if (lane == 0 && r != 0ull) {
+            atomicAdd(&pw.counters[CGRT_CNT_RAYS], r);
+            atomicAdd(&pw.counters[CGRT_CNT_HITPOINTS], hh);
         }
     }
 }

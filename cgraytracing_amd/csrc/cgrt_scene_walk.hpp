@@ -78,6 +78,32 @@ __device__ __forceinline__ double sphere_len(V3 centre, double r2, V3 o, V3 d) {
 }
 __device__ __forceinline__ double sphere_len(const ObjRec &ob, V3 o, V3 d) { return sphere_len(ld3(ob.a), ob.s0, o, d); }
 
+// Plane::intersect's distance, objects.h:505-507: len = ((p - o) . n) / (d . n).  For a normal that is exactly +-e_k the two dot
+// products are +-(p_k - o_k) and +-d_k to the bit -- the other products are +-0 and adding +-0 to a non-zero double changes
+// nothing -- and (-x) / (-y) rounds like x / y, so len is (p_k - o_k) / d_k: one subtraction and the division instead of three
+// subtractions and two dot products (five planes a ray: ~60 of a plane-bound ray's instructions).  Only when that numerator or
+// denominator is ZERO does the sign of the zero the general expression produces matter (+-inf, NaN): those lanes -- a ray
+// exactly parallel to the plane, an origin exactly in it -- take the general expression.  Called by all lanes of the wave.
+__device__ __forceinline__ double plane_len(const ObjRec &ob, V3 pn, V3 o, V3 d) {
+    const int ax = __builtin_amdgcn_readfirstlane(ob.axis);
+    double len;
+    if (ax >= 0) {
+        const double ok = ax == 0 ? o.x : (ax == 1 ? o.y : o.z), dk = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+        const double num = ob.a[ax] - ok;
+        len = num / dk;
+        const bool zero = (num == 0.0) || (dk == 0.0);
+        if (__ballot(zero) != 0ull) {
+            const V3 dd = ld3(ob.a) - o;
+            const double general = dot(dd, pn) / dot(d, pn);
+            if (zero) len = general;
+        }
+    } else {
+        const V3 dd = ld3(ob.a) - o;
+        len = dot(dd, pn) / dot(d, pn);
+    }
+    return len;
+}
+
 // The first 56 bytes of an ObjRec -- what the sphere loop needs of an object that is not in LDS (one scalar load)
 struct ObjHead {
     double a[3], b[3], s0;
@@ -225,28 +251,8 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
         } else if (kind == KIND_PLANE) {
             // Plane::intersect, objects.h:505-524
             const V3 pn = ld3(ob.b);
-            // len = ((p - o) . n) / (d . n).  For a normal that is exactly +-e_k the two dot products are +-(p_k - o_k) and
-            // +-d_k to the bit -- the other products are +-0 and adding +-0 to a non-zero double changes nothing -- and
-            // (-x) / (-y) rounds like x / y, so len is (p_k - o_k) / d_k: one subtraction and the division instead of three
-            // subtractions and two dot products (five planes a ray: ~60 of a plane-bound ray's instructions).  Only when that
-            // numerator or denominator is ZERO does the sign of the zero the general expression produces matter (+-inf, NaN):
-            // those lanes -- a ray exactly parallel to the plane, an origin exactly in it -- take the general expression.
-            const int ax = __builtin_amdgcn_readfirstlane(ob.axis);
-            double len;
-            if (ax >= 0) {
-                const double ok = ax == 0 ? o.x : (ax == 1 ? o.y : o.z), dk = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
-                const double num = ob.a[ax] - ok;
-                len = num / dk;
-                const bool zero = (num == 0.0) || (dk == 0.0);
-                if (__ballot(zero) != 0ull) {
-                    const V3 dd = ld3(ob.a) - o;
-                    const double general = dot(dd, pn) / dot(d, pn);
-                    if (zero) len = general;
-                }
-            } else {
-                const V3 dd = ld3(ob.a) - o;
-                len = dot(dd, pn) / dot(d, pn);
-            }
+            const double len_plane = plane_len(ob, pn, o, d);
+            double len = len_plane;
             const bool ph = len > 0;
             V3 nrm = pn;
             if (TREES) {

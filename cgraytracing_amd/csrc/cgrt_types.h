@@ -192,6 +192,7 @@ struct DeviceScene {
                          // sphere): tiles whose primary rays provably stay clear of the special objects' bounding spheres see
                          // diffuse spheres and planes only and may be rendered by the light kernel variant (cgrt_hip.hip)
     int32_t n_cover;
+    int32_t prim_finish;    // prim_obj >= 0 and no plane carries a bump tree: primary_walk_kernel may complete units (cgrt_primwalk.hpp)
     int32_t light_hf_only;  // light_trees and every plane's tree is an opaque bump floor with a grid (hfield): the light variant needs the
                             // height-field walk and nothing else of the tree code (HFONLY)
 };
