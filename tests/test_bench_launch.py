@@ -84,3 +84,16 @@ def test_dead_rank_stops_the_launch_quickly():
     dt = time.monotonic() - t0
     assert p.returncode == 7, (p.returncode, p.stdout, p.stderr)
     assert dt < 60, dt  # import torch + rendezvous start dominate; the gloo rendezvous timeout would be 30 min
+
+
+def test_cpu_baseline_falls_back_to_the_port(monkeypatch):
+    """`cpu_baseline.kind` is "reference" only where oracle/_ref/libcgrt_ref.so travelled with the tree; everywhere else the CPU
+    oracle port is timed and the line says so (keep that fallback tested).  A one-sample pass of the C2 frame."""
+    sys.path.insert(0, ROOT)
+    import backends
+    import bench
+    monkeypatch.setattr(backends, "have_ref", lambda: False)
+    cfg = dict(name="c2", W=1920, H=1080, spp=64)
+    out = bench.cpu_baseline(cfg, 1)
+    assert out["kind"] == "port" and out["ref_library_found"] is False and "NOT FOUND" in out["ref_library"]
+    assert out["cores"] == 1 and out["value"] > 0.1 and "spp=1" in out["sample"]
