@@ -29,6 +29,21 @@ static constexpr int kBezWaves = CGRT_BEZ_WAVES;  // waves per SIMD the Bezier v
 static constexpr int kTreeWaves = CGRT_TREE_WAVES;             // ... the tree-capable tile kernels
 static constexpr int kSchedTreeWaves = CGRT_SCHED_TREE_WAVES;  // ... the tree-capable scheduled kernels (unit queue + tile queue)
 
+// uniform_sampling_circle (sampling.h:35-43) on a sample's lens stream (cgrt_rng.hpp): attempt j takes the two draws of the
+// splitmix output z_j = fin64(key + (j + 1) G) -- what Stream::pair returns at position 2j, with the 64-bit multiply of the
+// counter replaced by a running addition (the same integers mod 2^64).  Shared by every kernel that starts a primary ray.
+__device__ __forceinline__ void lens_disc(uint64_t k_smp, double &sx, double &sy) {
+    uint64_t ctr = k_smp;
+    while (true) {
+        ctr += kGolden;
+        const uint64_t z = fin64(ctr);
+        const double ux = div_rand_max((uint32_t)(z >> 33)), uy = div_rand_max((uint32_t)((z >> 2) & 0x7fffffffu));
+        sx = ux * 2.0 - 1;
+        sy = uy * 2.0 - 1;
+        if (sx * sx + sy * sy < 1) break;
+    }
+}
+
 struct HitpointSink {
     double *rec;                // cap x 10 doubles: f(3) pos(3) normal(3) label
     unsigned long long *count;  // appended so far (may exceed cap: then the tail was dropped)
@@ -161,15 +176,8 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
     auto start_sample = [&](int smp) {  // main.cpp:204-209
         k_smp = sample_key(k_pix, (uint64_t)(g.sample_offset + smp));
         if (DOF) {
-            Stream rs(k_smp);  // purpose 0: the lens stream's key is the sample key
             double sx, sy;
-            while (true) {  // uniform_sampling_circle, sampling.h:35-43
-                double ux, uy;
-                rs.pair(ux, uy);
-                sx = ux * 2.0 - 1;
-                sy = uy * 2.0 - 1;
-                if (sx * sx + sy * sy < 1) break;
-            }
+            lens_disc(k_smp, sx, sy);  // purpose 0: the lens stream's key is the sample key
             o = camorg + mk(sx, sy, 0) * g.lens_radius;
             d = normalized(pof - o);
         } else {

@@ -190,15 +190,8 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
                     const V3 pof = mk(pc[3 * 64], pc[4 * 64], pc[5 * 64]);
                     const uint64_t k_pix = (uint64_t)__double_as_longlong(pc[6 * 64]);
                     if (DOF) {
-                        Stream rs(sample_key(k_pix, (uint64_t)(g.sample_offset + unit_smp)));
                         double sx, sy;
-                        while (true) {  // uniform_sampling_circle, sampling.h:35-43
-                            double ux, uy;
-                            rs.pair(ux, uy);
-                            sx = ux * 2.0 - 1;
-                            sy = uy * 2.0 - 1;
-                            if (sx * sx + sy * sy < 1) break;
-                        }
+                        lens_disc(sample_key(k_pix, (uint64_t)(g.sample_offset + unit_smp)), sx, sy);
                         o = camorg + mk(sx, sy, 0) * g.lens_radius;
                         d = normalized(pof - o);
                     } else {
