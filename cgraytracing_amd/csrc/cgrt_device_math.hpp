@@ -24,15 +24,51 @@ __device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-// vec3.h:36-44
+// The correctly rounded fp64 square root without the range scaling.  hipcc expands sqrt(x) into v_rsq_f64 and three fma
+// corrections -- which is what stands below, instruction for instruction -- wrapped in a scaling by 2^256 for x < 2^-767 (so that
+// the corrections do not underflow) and a final select for x = 0 / +inf: 20 VALU instructions, 7 of them range handling.  When no
+// active lane of the wave has such an x (nor a negative one or a NaN) the wrapping does nothing and is left out; otherwise the
+// whole wave takes the library form.  Same bits either way; a sphere-scene ray takes 4-5 square roots.
+__device__ __forceinline__ double sqrt_cr(double x) {
+    if (__ballot(!(x >= 0x1p-767 && x <= 0x1p1000)) != 0ull) return sqrt(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return g;
+}
+
+// vec3.h:36-44: len = sqrt(x*x + y*y + z*z); if (len > 0) every component *= 1 / len.
+// Both correctly rounded operations in their unwrapped form when no active lane needs the wrapping: sqrt_cr's condition on the sum
+// of squares puts len in [2^-384, 2^500], where hipcc's expansion of 1.0 / len (v_div_scale, v_rcp_f64, two refinements, one
+// residual correction, v_div_fmas, v_div_fixup: 11 instructions) scales nothing and fixes nothing up -- what is left is the 7
+// instructions below, the same bits.
 __device__ __forceinline__ V3 normalized(V3 a) {
-    double len = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
-    if (len > 0) {
-        double r = 1 / len;
-        a.x *= r;
-        a.y *= r;
-        a.z *= r;
+    const double s2 = a.x * a.x + a.y * a.y + a.z * a.z;
+    if (__ballot(!(s2 >= 0x1p-767 && s2 <= 0x1p1000)) != 0ull) {
+        const double len = sqrt(s2);
+        if (len > 0) {
+            const double r = 1 / len;
+            a.x *= r;
+            a.y *= r;
+            a.z *= r;
+        }
+        return a;
     }
+    const double len = sqrt_cr(s2);
+    double r = __builtin_amdgcn_rcp(len);
+    r = __builtin_fma(__builtin_fma(-len, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-len, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-len, r, 1.0), r, r);  // q = fma(fma(-len, q0, 1), r, q0) with q0 = 1.0 * r
+    a.x *= r;
+    a.y *= r;
+    a.z *= r;
     return a;
 }
 // vec3.h:95-97, Sarrus with the reference's association

@@ -358,7 +358,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                             d = refl_dir;
                         } else {
                             const V3 refr_dir =
-                                normalized(d * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
+                                normalized(d * nnt - n_old * ((into ? 1 : -1) * (ddn * nnt + sqrt_cr(cos2t))));
                             const double a = nt - nc, b = nt + nc, R0 = a * a / (b * b);
                             const double c = 1 - (into ? -ddn : dot(refr_dir, n_old));
                             const double Re = R0 + (1 - R0) * c * c * c * c * c;

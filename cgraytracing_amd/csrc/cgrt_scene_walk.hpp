@@ -69,7 +69,7 @@ __device__ __forceinline__ double sphere_len(V3 centre, double r2, V3 o, V3 d) {
     if (!(tca < 0 && l2 > r2)) {
         const double d2 = l2 - tca * tca;
         if (!(d2 > r2)) {
-            const double thc = sqrt(r2 - d2);
+            const double thc = sqrt_cr(r2 - d2);
             const double t0 = tca - thc, t1 = tca + thc;
             len = (t0 < 0) ? t1 : t0;
         }
