@@ -8,6 +8,14 @@
 
 using namespace cgrt;
 
+#ifdef CGRT_UTIL
+__device__ unsigned long long g_util[32];
+#define UTILP(k, pred) do { const unsigned long long m_ = __ballot(pred); const unsigned long long a_ = __ballot(true); if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1) { atomicAdd(&g_util[2*(k)], 1ull); atomicAdd(&g_util[2*(k)+1], (unsigned long long)__popcll(m_)); } } while (0)
+#else
+#define UTILP(k, pred) do {} while (0)
+#endif
+#define UTIL(k) UTILP(k, true)
+
 // =====================================================================================================
 // device math: the reference's Vec3 (vec3.h:11-119), same operation order, no contraction
 // =====================================================================================================

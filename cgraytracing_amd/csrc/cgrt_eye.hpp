@@ -275,6 +275,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
             if (__ballot(have) == 0ull) break;  // every lane of the wave has drained its pixel
         }
         wave_iters++;
+        UTILP(heavy ? 0 : 11, have);
         // All 64 lanes enter the scene walk together (lanes without a ray carry on == false): the object list
         // is wave-uniform, so its control flow stays scalar.
         RayKey rk{k_smp, path, false, 0u};
@@ -283,6 +284,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
             rk.pre_obj = g.prim_obj;
             rk.pre_len = pre_len;
             rk.pre_tri = pre_tri;
+            rk.pre_counter = pre_tri >= 0 ? 1 : 0;
             pre_valid = false;
         }
         const SceneHit hit =
@@ -307,6 +309,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                 }
                 const double refl = ob.refl, transp = ob.transp;
                 if (refl < kEps && transp < kEps) {
+                    UTIL(heavy ? 7 : 12);
                     // diffuse: the reference stores Hitpoint{f*adj,...} (main.cpp:85-100); we accumulate it
                     const V3 hf = mulv(f, adj);
                     if (heavy) {
@@ -346,6 +349,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                         path = path * 2;
                         have = true;
                     } else if (GLASS) {
+                        UTIL(heavy ? 8 : 13);
                         // glass, main.cpp:135-157
                         const double nc = 1.0, nt = 1.33;
                         const double nnt = into ? nc / nt : nt / nc;
@@ -407,6 +411,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                 have = true;
             }
             if (GLASS && !have && sp > 0) {
+                UTIL(heavy ? 10 : 14);
                 --sp;
                 if (sp < kLdsLevels) {
                     const double *q = reinterpret_cast<const double *>(lslot + sp * TG::level_bytes) + threadIdx.x;

@@ -58,7 +58,16 @@ struct RayKey {
     bool pre_valid = false;
     int32_t pre_obj = -1, pre_tri = -1;
     double pre_len = 0;
+    int32_t pre_counter = 0;  // improvements (a transparent owner's normal depends on their parity)
 };
+
+// TriangleMesh::intersect's early-out (see intersect_scene): false = the ray cannot hit a triangle of the mesh bounded by the
+// sphere (ob.a, ob.s0)
+__device__ __forceinline__ bool mesh_may_hit(const ObjRec &ob, V3 o, V3 d) {
+    const V3 lc = ld3(ob.a) - o;
+    const double tca = dot(lc, d), l2 = dot(lc, lc), dd = dot(d, d), r2 = ob.s0;
+    return !(tca < 0 && l2 > r2) && !(l2 * dd - tca * tca > r2 * dd);
+}
 
 // Sphere::intersect, objects.h:45-68: the hit distance, or +inf-like kInf (never < nearest) on a miss
 __device__ __forceinline__ double sphere_len(V3 centre, double r2, V3 o, V3 d) {
@@ -165,6 +174,7 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
     none.len = kInf;
     none.tri = -1;
     none.counter = 0;
+    UTILP(1, on);
     if (!on) return none;
     if (HFONLY || (opaque && T.hfield >= 0)) {  // bump floor: walk the grid instead of the tree (same triangles, same test)
         const HFieldRec H = load_uniform(sc.hfields + T.hfield);
@@ -286,9 +296,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             // 1e-3 to spare), or that points away from it from outside, cannot hit a triangle, whatever boxes it crosses: the
             // tree would return nothing that counts.  Most waves of a frame never come near the mesh and skip the
             // tree call, its three divisions and its root fetch altogether (measured: 7.7 of C4's 42.7 ms at spp 64).
-            const V3 lc = ld3(ob.a) - o;
-            const double tca = dot(lc, d), l2 = dot(lc, lc), dd = dot(d, d), r2 = ob.s0;
-            const bool may = on && !(tca < 0 && l2 > r2) && !(l2 * dd - tca * tca > r2 * dd);
+            const bool may = on && mesh_may_hit(ob, o, d);
             // PRE: a lane whose hit in this object is already known (a fresh unit's primary ray, cgrt_primwalk.hpp) does not walk
             const bool known = PRE && rk.pre_valid && rk.pre_obj == i;
             const bool walk = may && !known;
@@ -308,7 +316,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 if (PRE && known) {
                     h.len = rk.pre_len;
                     h.tri = rk.pre_tri;
-                    h.counter = rk.pre_tri >= 0 ? 1 : 0;
+                    h.counter = rk.pre_counter;
                 }
                 if (may && h.counter > 0 && h.len < best.t) {
                     V3 nrm = tree_normal(sc.tris + load_uniform(&sc.trees[tr].tri_begin), h, d);

@@ -101,6 +101,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
     while (true) {
         int leaf_begin = 0, leaf_cnt_tris = -1;
         while (i < nnodes) {
+            UTIL(2);
             // one 32-byte record = two 16-byte loads
             const float4 q0 = reinterpret_cast<const float4 *>(nodes + i)[0];  // lo.x lo.y lo.z hi.x
             const float4 q1 = reinterpret_cast<const float4 *>(nodes + i)[1];  // hi.y hi.z skip leaf
@@ -120,6 +121,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             break;
         }
         if (leaf_cnt_tris < 0) break;  // no further leaf for this lane
+        UTIL(3);
         // leaf scan, objects.h:273-289.  The reference's leaves are loose (7.5 triangles under one box, a ray that touches
         // the box misses most of them), and a triangle test is ~110 fp64 instructions on 72 bytes.  With tboxes (transparent
         // owners: every touched leaf must be scanned, in order, for the improvement counter) each triangle is first tested
@@ -133,6 +135,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             const NodeRec *bp = tboxes + leaf_begin;
             unsigned cand = 0;
             for (int k = 0; k < leaf_cnt_tris; k++) {
+                UTIL(4);
                 const float4 q0 = reinterpret_cast<const float4 *>(bp + k)[0];  // lo.x lo.y lo.z hi.x
                 const float2 q1 = reinterpret_cast<const float2 *>(bp + k)[2];  // hi.y hi.z
                 float tn, tf;
@@ -144,6 +147,7 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             while (cand != 0u) {
                 const int k = __ffs((int)cand) - 1;
                 cand &= cand - 1u;
+                UTIL(5);
                 if (STATS) n_tri++;
                 const V3 pa = ld3(tp[k].pa), e1 = ld3(tp[k].e1), e2 = ld3(tp[k].e2);
                 const V3 s = pa - o;
