@@ -197,8 +197,8 @@ __device__ __forceinline__ TreeHit tree_hit(const DeviceScene &sc, const LdsAux 
         return tree_intersect<STATS, true>(nodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri);
     }
     const NodeRec *tb = sc.tboxes + T.tbox_begin;
-    if (cached) return tree_intersect<STATS, false>(aux.lnodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri, tb);
-    return tree_intersect<STATS, false>(nodes, tris, T.nnodes, o, d, r32, bound, n_node, n_tri, tb);
+    if (cached) return tree_intersect_lq<STATS>(aux.lnodes, tris, T.nnodes, o, d, r32, n_node, n_tri, tb);
+    return tree_intersect_lq<STATS>(nodes, tris, T.nnodes, o, d, r32, n_node, n_tri, tb);
 }
 
 // objs[0 .. n_lds): the LDS-resident list; objects n_lds .. n_objs-1 (scenes with more than kLdsObjsMax objects) come from
