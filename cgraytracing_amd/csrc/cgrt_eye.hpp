@@ -898,6 +898,7 @@ __global__ void intersect_rays_kernel(DeviceScene sc, int obj, const double *__r
     uint32_t a = 0, b = 0;
     const V3 o = ld3(org + 3 * ii), d = ld3(dir + 3 * ii);
     DeviceScene one = sc;
+    one.prun_begin = one.prun_end = 0;  // the list handed down is this one object
     RayKey rk{keys ? keys[ii] : 0ull, 1, true, 0u};
     const LdsAux aux{&bl, nullptr};
     SceneHit h = intersect_scene<true, true, false, false>(sc.objs + obj, 1, 1, one, o, d, rk, on, aux, a, b);

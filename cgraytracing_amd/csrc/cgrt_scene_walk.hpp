@@ -113,6 +113,56 @@ __device__ __forceinline__ double plane_len(const ObjRec &ob, V3 pn, V3 o, V3 d)
     return len;
 }
 
+// A run of axis-aligned planes (DeviceScene::prun_begin/end), tested as a group.  Each plane's distance is the correctly rounded
+// quotient (p_k - o_k) / d_k (plane_len above): five planes, five fp64 divisions of ~28 instructions, of which only the smallest
+// positive one is used.  Here every plane first gets an APPROXIMATE distance t~ = fl32(p_k - o_k) * rcp32(d_k), relative error
+// below 2^-21 (two conversions, the hardware reciprocal's 1 ulp, one product): if the smallest positive t~ is below the second
+// smallest by a factor of more than 1 + 2^-14, the exact quotient of that plane is smaller than every other plane's by more than
+// 1 + 2^-15, so its ROUNDED quotient is strictly the smallest too -- it is what the loop over the planes would have kept, whatever
+// the order -- and one division yields it.  Lanes for which that does not hold (two planes within 2^-14 of each other: a ray
+// through an edge of the room; a zero or tiny numerator or denominator, where plane_len takes its general form; distances beyond
+// 1e9, near kInf) are told apart (`unsure`) and go through the planes one by one as before.  Called by all lanes of the wave.
+struct PlaneRunHit {
+    double len;   // the winner's distance (only if id >= 0)
+    int id;       // the plane of the run with the smallest positive distance, or -1
+    bool unsure;  // this lane must take the planes one by one
+};
+__device__ __forceinline__ PlaneRunHit plane_run(const ObjRec *__restrict__ objs, int begin, int end, V3 o, V3 d) {
+    const float r32[3] = {__builtin_amdgcn_rcpf((float)d.x), __builtin_amdgcn_rcpf((float)d.y), __builtin_amdgcn_rcpf((float)d.z)};
+    const float inf32 = __int_as_float(0x7f800000);
+    float t1 = inf32, t2 = inf32;  // smallest and second smallest positive approximate distance
+    double wnum = 0.0;
+    int wax = 0;
+    PlaneRunHit h;
+    h.id = -1;
+    // zero or tiny operands (plane_len's general form; fp32 underflow), huge or non-finite distances: not decided here
+    h.unsure = !(fabs(d.x) > 1e-30) || !(fabs(d.y) > 1e-30) || !(fabs(d.z) > 1e-30);
+    for (int j = begin; j < end; j++) {
+        const int ax = __builtin_amdgcn_readfirstlane(objs[j].axis);
+        const double p = objs[j].a[ax];
+        double num;
+        float t;
+        if (ax == 0) { num = p - o.x; t = (float)num * r32[0]; }       // (wave-uniform branches)
+        else if (ax == 1) { num = p - o.y; t = (float)num * r32[1]; }
+        else { num = p - o.z; t = (float)num * r32[2]; }
+        h.unsure = h.unsure || !(fabs(num) > 1e-30) || !(fabsf(t) < 1e9f);
+        if (t > 0.f) {
+            if (t < t1) {
+                t2 = t1;
+                t1 = t;
+                h.id = j;
+                wnum = num;
+                wax = ax;
+            } else if (t < t2) {
+                t2 = t;
+            }
+        }
+    }
+    h.unsure = h.unsure || (h.id >= 0 && !(t2 > t1 * 1.00006103515625f));  // 1 + 2^-14
+    h.len = wnum / (wax == 0 ? d.x : (wax == 1 ? d.y : d.z));
+    return h;
+}
+
 // The first 56 bytes of an ObjRec -- what the sphere loop needs of an object that is not in LDS (one scalar load)
 struct ObjHead {
     double a[3], b[3], s0;
@@ -237,7 +287,25 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
     // 1/d for the box tests: three fp64 divisions (~100 instructions), paid only by waves that reach a tree
     V3 inv = mk(0, 0, 0);
     bool inv_ready = false;  // wave-uniform
-    for (int i = 0; i < (SPILL ? n_objs : n_lds); i++) {
+    // The leading run of axis-aligned planes (plane_run above), before the loop: when every lane of the wave is sure of its
+    // result the loop starts behind the run; otherwise it starts at 0 and the run's planes count for the unsure lanes only.
+    bool run_unsure = false;
+    int run_end = 0, i_first = 0;
+    if (!HFONLY && !SPH && sc.prun_end > 0) {  // (wave-uniform)
+        run_end = sc.prun_end;
+        const PlaneRunHit ph = plane_run(objs, 0, run_end, o, d);
+        run_unsure = ph.unsure;
+        if (!ph.unsure && ph.id >= 0 && ph.len > 0) {  // best.t == kInf here: `len < nearest` is the loop's own test
+            if (ph.len < best.t) {
+                best.t = ph.len;
+                best.id = ph.id;
+                best.n = ld3(objs[ph.id].b);
+                nsrc = 1;
+            }
+        }
+        if (__ballot(run_unsure) == 0ull) i_first = run_end;
+    }
+    for (int i = i_first; i < (SPILL ? n_objs : n_lds); i++) {
         const ObjRec *obp = objs + i;
         if (SPILL && i >= n_lds) {
             // beyond the LDS list: the record is staged in this wave's LDS slot (eight 16-byte pieces) and read from there,
@@ -250,6 +318,8 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             obp = aux.spill;
         }
         const ObjRec &ob = *obp;
+        // inside the plane run (some lane was unsure): only the unsure lanes take a plane's result from here
+        const bool planes_one_by_one = !(i < run_end) || run_unsure;
         const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
         if (kind == KIND_SPHERE) {
             const double len = sphere_len(ob, o, d);
@@ -283,7 +353,7 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                     }
                 }
             }
-            if (ph && len < best.t) {
+            if (planes_one_by_one && ph && len < best.t) {
                 best.t = len;
                 best.id = i;
                 best.n = nrm;

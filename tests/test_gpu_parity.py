@@ -562,6 +562,35 @@ def test_random_scenes_match_oracle_exactly(gpu_ready, orc, seed):
     assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
 
 
+@pytest.mark.parametrize("variant", ["edges", "origin_in_a_plane", "thin_lens"])
+def test_plane_group_test_edges_corners_and_degenerate_rays(gpu_ready, orc, variant):
+    """The leading run of axis-aligned planes is tested as a group (cgrt_scene_walk.hpp plane_run): approximate distances pick
+    the winner, one exact division yields its distance, and a lane whose two nearest planes are within 2^-14 of each other -- or
+    that has a zero numerator or denominator -- takes the planes one by one.  A room built so that whole pixel columns and
+    rows look exactly into its edges (and four pixels into its corners): with the pinhole camera at (0,0,-10) and half-width
+    10 the rays of column w = 48 of 64 have x : z = 5 : 10 and meet the walls x = 12 and z = 14 on their common edge; rows
+    likewise for floor and ceiling.  The centre column and row have d.x = 0 resp. d.y = 0 (a ray parallel to two walls).
+    `origin_in_a_plane` adds a plane through the camera (numerator 0 for every primary ray); `thin_lens` moves the origins off
+    the axis.  One wall is a mirror, so secondary rays start on a plane.  Everything must equal the oracle exactly."""
+    import cgraytracing_amd as cg
+    P = scenes.Plane
+    objs = [P((0.0, -12.0, 0), (0, 1, 0), (0.9, 0.2, 0.2), 0.0, 0.0), P((12.0, 0.0, 0), (-1, 0, 0), (0.2, 0.9, 0.2), 0.0, 0.0),
+            P((-12.0, 0.0, 0), (1, 0, 0), (0.2, 0.2, 0.9), 0.8, 0.0), P((0.0, 0.0, 14.0), (0, 0, -1), (0.9, 0.9, 0.2), 0.0, 0.0),
+            P((0.0, 12.0, 0), (0, -1, 0), (0.2, 0.9, 0.9), 0.0, 0.0)]
+    if variant == "origin_in_a_plane":
+        objs.append(P((0.0, 0.0, -10.0), (0, 0, 1), (0.5, 0.5, 0.5), 0.0, 0.0))
+    objs.append(scenes.Sphere((3.0, -4.0, 6.0), 2.0, (0.7, 0.7, 0.7), 0.0, 0.0))
+    cam = scenes.cam_dof() if variant == "thin_lens" else scenes.cam_pinhole()
+    W = H = 64
+    for spp in (1, 5):  # image order, and the scheduled path with its light-tile launch
+        want = BackendScene(orc, objs).trace_grid(cam, W, H, spp, 5, seed=4242)
+        with cg.Scene(objs) as sc:
+            got = sc.trace_grid_host(W, H, spp, cam, 5, 4242)
+        assert got["nrays"] == want["nrays"]
+        assert np.array_equal(got["nhit"], want["nhit"])
+        assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
+
+
 @pytest.mark.parametrize("which", ["sphere", "plane", "mesh", "vase"])
 def test_cpp_object_intersect_matches_oracle(gpu_ready, orc, which):
     """Object::intersect / intersect_batch of include/cgrt_host.hpp -- the reference's virtual (objects.h:20) -- called from

@@ -20,6 +20,10 @@ def demangle_variant(name):
     if m:
         t = [int(x) for x in m.groups()]
         return "trace_grid_kernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,HPS=%d,NT=%d,HEAVY=%d>" % tuple(t)
+    m = re.match(r"_Z17trace_grid_kernelIL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)ELi(\d+)EL?b(\d)EL?b(\d)EE", name)
+    if m:
+        t = [int(x) for x in m.groups()]
+        return "trace_grid_kernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,HPS=%d,NT=%d,SPILL=%d,HFONLY=%d>" % tuple(t)
     m = re.match(r"_Z23trace_grid_sched_kernelIL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)EL?b(\d)ELi(\d+)EE", name)
     if m:
         t = [int(x) for x in m.groups()]
@@ -28,9 +32,12 @@ def demangle_variant(name):
     if m:
         t = [int(x) for x in m.groups()]
         return "trace_grid_kernel<TREES=%d,BEZ=%d,DOF=%d,GLASS=%d,SPH=%d,STATS=%d,HPS=%d,NT=%d>" % tuple(t)
-    m = re.match(r"_Z19photon_trace_kernelILb(\d)EE", name)
+    m = re.search(r"19photon_trace_kernelILb(\d)ELb(\d)EE", name)
     if m:
-        return "photon_trace_kernel<BEZ=%s>" % m.group(1)
+        return "photon_trace_kernel<BEZ=%s,SPILL=%s>" % m.groups()
+    m = re.search(r"19primary_walk_kernelILb(\d)EE", name)
+    if m:
+        return "primary_walk_kernel<DOF=%s>" % m.group(1)
     m = re.match(r"_Z(\d+)", name)
     if m:
         k = int(m.group(1))
