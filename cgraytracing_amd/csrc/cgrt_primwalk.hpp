@@ -104,7 +104,20 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
                 // the rest of the scene walk (main.cpp:55-63): every object in order, the mesh's hit at the mesh's position
                 double bt = kInf;
                 int bid = -1;
-                for (int i = 0; i < sc.n_objs; i++) {
+                // the leading run of axis-aligned planes as a group, as in intersect_scene (cgrt_scene_walk.hpp plane_run)
+                int i_first = 0, run_end = 0;
+                bool run_unsure = false;
+                if (sc.prun_end > 0 && pw.obj >= sc.prun_end) {
+                    run_end = sc.prun_end;
+                    const PlaneRunHit ph = plane_run(lobjs, 0, run_end, o, d);
+                    run_unsure = ph.unsure;
+                    if (!ph.unsure && ph.id >= 0 && ph.len > 0 && ph.len < bt) {
+                        bt = ph.len;
+                        bid = ph.id;
+                    }
+                    if (__ballot(run_unsure) == 0ull) i_first = run_end;
+                }
+                for (int i = i_first; i < sc.n_objs; i++) {
                     const ObjRec &ob = lobjs[i];
                     const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
                     double len = kInf;
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
                         const double l = plane_len(ob, ld3(ob.b), o, d);
                         if (l > 0) len = l;  // (no plane of such a scene carries a bump tree)
                     }
-                    if (len < bt) {
+                    if ((!(i < run_end) || run_unsure) && len < bt) {
                         bt = len;
                         bid = i;
                     }
