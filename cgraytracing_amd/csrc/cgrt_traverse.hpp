@@ -83,11 +83,12 @@ struct TreeHit {
 // ones and a leaf holding a triangle that ties with the bound is still scanned: (len, triangle) stay exact.
 //
 // An opaque owner's own hierarchy goes further: it reaches down to groups of <= 4 single triangles and is walked in a 4-wide
-// form (tree_intersect_wide below); this routine serves transparent owners (PRUNE = false) and CGRT_TREE=ref.
+// form (tree_intersect_wide below), a transparent owner's is walked by tree_intersect_lq; this routine serves what is left: opaque
+// owners whose stackless hierarchy is walked as it is (CGRT_TREE=ref; a bump floor without a grid).
 template <bool STATS, bool PRUNE>
 __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                   int nnodes, V3 o, V3 d, const Ray32 &r32, double bound, uint32_t &n_node,
-                                                  uint32_t &n_tri, const NodeRec *__restrict__ tboxes = nullptr) {
+                                                  uint32_t &n_tri) {
     float bound32 = PRUNE ? __double2float_ru(bound) : 0.f;  // >= bound: an entry distance above it is above bound
     TreeHit r;
     r.len = kInf;
@@ -122,53 +123,10 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
         }
         if (leaf_cnt_tris < 0) break;  // no further leaf for this lane
         UTIL(3);
-        // leaf scan, objects.h:273-289.  The reference's leaves are loose (7.5 triangles under one box, a ray that touches
-        // the box misses most of them), and a triangle test is ~110 fp64 instructions on 72 bytes.  With tboxes (transparent
-        // owners: every touched leaf must be scanned, in order, for the improvement counter) each triangle is first tested
-        // against its own grown fp32 box -- 32 bytes, ~25 instructions, a superset test like the nodes' -- and only
-        // triangles whose box the ray touches get the exact test; hits, their order and the counter are unchanged.
+        // leaf scan, objects.h:273-289
         double leaf_len = kInf;
         int leaf_tri = -1, leaf_cnt = 0;
         const TriRec *tp = tris + leaf_begin;
-        if (tboxes) {
-            // pass 1: the boxes, all lanes together -- a bit per triangle whose box the ray touches
-            const NodeRec *bp = tboxes + leaf_begin;
-            unsigned cand = 0;
-            for (int k = 0; k < leaf_cnt_tris; k++) {
-                UTIL(4);
-                const float4 q0 = reinterpret_cast<const float4 *>(bp + k)[0];  // lo.x lo.y lo.z hi.x
-                const float2 q1 = reinterpret_cast<const float2 *>(bp + k)[2];  // hi.y hi.z
-                float tn, tf;
-                slab32(r32, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn, tf);
-                if ((tf > 0.f) && (tn <= tf)) cand |= 1u << k;
-            }
-            // pass 2: the exact tests, each lane on ITS candidates in ascending order (the leaf's order, objects.h:273-289):
-            // the wave runs as many rounds as its busiest lane has candidates instead of one round per triangle of the leaf
-            while (cand != 0u) {
-                const int k = __ffs((int)cand) - 1;
-                cand &= cand - 1u;
-                UTIL(5);
-                if (STATS) n_tri++;
-                const V3 pa = ld3(tp[k].pa), e1 = ld3(tp[k].e1), e2 = ld3(tp[k].e2);
-                const V3 s = pa - o;
-                const double det1 = det3(d, e1, e2);
-                const double det2 = det3(s, e1, e2);
-                const double det3_ = det3(d, s, e2);
-                const double det4 = det3(d, e1, s);
-                const double sg = det1 > 0.0 ? 1.0 : -1.0;
-                const double a1 = det1 * sg;
-                const bool ok = (det1 != 0.0) && (det2 * sg > 0.0) && (det3_ * sg >= 0.0) && (det4 * sg >= 0.0) &&
-                                ((det3_ + det4) * sg <= a1);
-                if (ok) {
-                    const double len = det2 / det1;
-                    if (len < leaf_len) {
-                        leaf_len = len;
-                        leaf_tri = leaf_begin + k;
-                        leaf_cnt++;
-                    }
-                }
-            }
-        } else {
         // one triangle ahead: the next record is requested before the current one is tested (every request is used
         // except the repeat of the last one, so this adds no traffic)
         V3 pa = ld3(tp[0].pa), e1 = ld3(tp[0].e1), e2 = ld3(tp[0].e2);
@@ -197,7 +155,6 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
             e1 = ne1;
             e2 = ne2;
         }
-        }
         if (leaf_cnt > 0) {
             // objects.h:295-313: the left result survives only if strictly nearer => the LATER leaf of the reference's
             // sequence wins ties.  Spelled out on the leaf's position, because the hierarchy above the leaves need not
@@ -220,6 +177,11 @@ __device__ __forceinline__ TreeHit tree_intersect(const NodeRec *__restrict__ no
 // =====================================================================================================
 // Transparent owners: the same walk with the touched leaves queued
 // =====================================================================================================
+// Every leaf the ray touches must be scanned, in order, for the improvement counter.  The reference's leaves are loose (7.5
+// triangles under one box, a ray that touches the box misses most of them) and a triangle test is ~110 fp64 instructions on 72
+// bytes, so each triangle is first tested against its own grown fp32 box (`tboxes`: 32 bytes, ~25 instructions, a superset test
+// like the nodes') and only triangles whose box the ray touches get the exact test; hits, their order and the counter are unchanged.
+//
 // tree_intersect above alternates "every lane walks until it stands on a leaf" and "scan the leaves".  Measured on the glass bunny
 // (tools/util_probe.py): a lane needs 4.4 node steps to its next leaf on average, the slowest lane of the wave 12.6 -- 19 of 64
 // lanes are active in a node step, and the node steps (a chain of dependent LDS fetches) are what the walk's time is made of.
