@@ -503,8 +503,7 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                 tt += __shfl_xor(tt, off);
             }
         }
-        // a wave that traced nothing (its tile belongs to another launch, or lies outside the image) adds nothing: same-address
-        // atomics serialise in L2 at ~16 ns each, which 260 000 idle waves would turn into milliseconds
+        // (`counters` is the workgroup's LDS array, see wg_counters_begin) a wave that traced nothing adds nothing
         if (lane == 0 && (r | (unsigned long long)wave_iters) != 0ull) {
             atomicAdd(&counters[CGRT_CNT_RAYS], r);
             atomicAdd(&counters[CGRT_CNT_HITPOINTS], hh);
@@ -517,14 +516,34 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
     }
 }
 
+// Counters.  A wave adds its sums to counters that all waves of the launch share; same-address atomics are served one after the
+// other, ~12 ns each, by the memory side -- measured: a 4096x4096 frame of plane-only rays took 9.5 ms whatever its sample count
+// (1, 4 or 16), 262 144 waves x 3 atomics.  So a workgroup collects its waves' sums in LDS (wg_counters_begin/end around the
+// body or bodies it runs: the body's `counters` IS that LDS array) and adds them to the launch's counters once, when it ends:
+// a quarter of the atomics for one-tile workgroups, a few thousand per launch for the persistent ones.
+__device__ __forceinline__ unsigned long long *wg_counters_begin(unsigned long long *wg, const unsigned long long *counters) {
+    if (!counters) return nullptr;  // (a kernel argument: uniform)
+    if (threadIdx.x < CGRT_NCOUNTERS) wg[threadIdx.x] = 0ull;
+    __syncthreads();
+    return wg;
+}
+__device__ __forceinline__ void wg_counters_end(const unsigned long long *wg, unsigned long long *counters) {
+    if (!counters) return;
+    __syncthreads();  // every wave of the workgroup has left its last body
+    if (threadIdx.x < CGRT_NCOUNTERS && wg[threadIdx.x] != 0ull) atomicAdd(&counters[threadIdx.x], wg[threadIdx.x]);
+}
+
 // One launch = tile workgroups only (probe, image order, Hitpoint capture) ...
 template <bool TREES, bool BEZ, bool DOF, bool GLASS, bool SPH, bool STATS, bool HPS = false, int NT = 256, bool SPILL = false, bool HFONLY = false>
 __global__ __launch_bounds__(NT, BEZ ? kBezWaves : ((TREES && !HFONLY) ? kTreeWaves : 4)) void trace_grid_kernel(DeviceScene sc, GridParams g, float *__restrict__ rgb,
                                                              uint32_t *__restrict__ nhit_out,
                                                              unsigned long long *__restrict__ counters,
                                                              HitpointSink hps = HitpointSink{nullptr, nullptr, 0}) {
-    trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, HPS, NT, false, SPILL, HFONLY>(sc, g, rgb, nhit_out, counters, hps, (int)blockIdx.x,
+    __shared__ unsigned long long wg_cnt[CGRT_NCOUNTERS];
+    unsigned long long *wc = wg_counters_begin(wg_cnt, counters);
+    trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, HPS, NT, false, SPILL, HFONLY>(sc, g, rgb, nhit_out, wc, hps, (int)blockIdx.x,
                                                                                        (int)gridDim.x);
+    wg_counters_end(wg_cnt, counters);
 }
 // ... or the scheduled form: the first g.heavy_blocks workgroups serve the heavy tiles' unit queue, the others are the tile
 // workgroups.  Two bodies in one kernel: the dispatcher starts workgroups in index order, so the heavy work starts first and
@@ -537,16 +556,19 @@ __global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? kSchedTreeWaves : 4)
                                                                                          unsigned long long *__restrict__ counters) {
     const HitpointSink none{nullptr, nullptr, 0};
     const bool heavy_first = (int)blockIdx.x < g.heavy_blocks;
+    __shared__ unsigned long long wg_cnt[CGRT_NCOUNTERS];
+    unsigned long long *wc = wg_counters_begin(wg_cnt, counters);
     if (NT == 64) {
         // one-wave workgroups (Bezier scenes): one workgroup per 16x4 tile behind the heavy ones -- a slot is handed on the
         // moment its wave ends, and measured on a C5 band the queue form bought nothing (34.6 vs 34.9 ms) while its larger
         // kernel cost 4 %
         if (heavy_first)
-            trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, counters, none, 0, 1);
+            trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, wc, none, 0, 1);
         else
-            trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, false>(sc, g, rgb, nhit_out, counters, none,
+            trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, false>(sc, g, rgb, nhit_out, wc, none,
                                                                                   (int)blockIdx.x - g.heavy_blocks,
                                                                                   (int)gridDim.x - g.heavy_blocks);
+        wg_counters_end(wg_cnt, counters);
         return;
     }
     // With a tile queue (g.border) both kinds of work come from queues: a workgroup serves its own kind until that queue is
@@ -557,7 +579,7 @@ __global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? kSchedTreeWaves : 4)
     for (int phase = 0; phase < 2; phase++) {
         if ((phase == 0) == heavy_first) {
             if (queued || heavy_first)
-                trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, counters, none, 0, 1);
+                trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, true>(sc, g, rgb, nhit_out, wc, none, 0, 1);
         } else {
             const unsigned n_entries = queued ? load_uniform(g.plan + 3) : (heavy_first ? 0u : 1u);
             unsigned served = 0;
@@ -571,11 +593,12 @@ __global__ __launch_bounds__(NT, BEZ ? kBezWaves : (TREES ? kSchedTreeWaves : 4)
                 }
                 if (e >= n_entries) break;
                 trace_grid_body<TREES, BEZ, DOF, GLASS, SPH, STATS, false, NT, false>(
-                    sc, g, rgb, nhit_out, counters, none, queued ? (int)g.border[e] : (int)blockIdx.x - g.heavy_blocks,
+                    sc, g, rgb, nhit_out, wc, none, queued ? (int)g.border[e] : (int)blockIdx.x - g.heavy_blocks,
                     queued ? -1 : (int)gridDim.x - g.heavy_blocks);
             }
         }
     }
+    wg_counters_end(wg_cnt, counters);
 }
 
 // CGRT_GRID_SPLIT_SAMPLES, second step: chunk sums added in chunk order, scaled, rounded once to fp32.

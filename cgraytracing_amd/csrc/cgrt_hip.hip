@@ -643,7 +643,7 @@ static GridVariant grid_variant(const cgrt_scene *s, const cgrt_camera *cam, con
     v.sph = !v.trees && s->dev.all_spheres != 0;
     v.stats = (grid->flags & CGRT_GRID_STATS) != 0 && s->dev.has_mesh != 0 && !v.bez;
     v.nt = v.bez ? 64 : kThreads;
-    v.sched = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER)) &&  // (CGRT_FORCE_REORDER, a measurement aid, is not reflected here)
+    v.sched = grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && (!(s->dev.has_mesh == 0 && s->dev.has_bezier == 0) || (grid->flags & CGRT_GRID_FORCE_REORDER)) &&  // (CGRT_FORCE_REORDER, a measurement aid, is not reflected here)
               ((size_t)((grid->width + kWaveTileW - 1) / kWaveTileW) * ((grid->rows + kWaveTileH - 1) / kWaveTileH)) > 1;
     return v;
 }
@@ -758,12 +758,14 @@ int cgrt_trace_grid(const cgrt_scene *s, const cgrt_camera *cam, const cgrt_grid
     const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW, wtiles_y = (g.rows + kWaveTileH - 1) / kWaveTileH;
     const size_t n_wt = (size_t)wtiles_x * wtiles_y;
     static const bool env_force_reorder = [] { const char *e = std::getenv("CGRT_FORCE_REORDER"); return e && *e && *e != '0'; }();
-    // Sphere-only scenes are left in image order: without a tree or a Newton solve behind a ray, a tile's cost varies only
-    // with the size of its ray trees (<= 31 rays per sample), the per-lane sample loop already keeps 97 % of the lanes busy,
-    // and measured on C2 the unit queue costs 13 % more VALU instructions (at 93 % VALU busy) and 0.9 GB of deferred values
-    // per frame for a gain within the noise (4.0-4.2 ms either way).
+    // Scenes of spheres and plain planes are left in image order: without a tree or a Newton solve behind a ray, a tile's cost
+    // varies only with the size of its ray trees (<= 31 rays per sample), the per-lane sample loop already keeps 97 % of the
+    // lanes busy, and measured on C2 the unit queue costs 13 % more VALU instructions (at 93 % VALU busy) and 0.9 GB of deferred
+    // values per frame for a gain within the noise (4.0-4.2 ms either way); a room of five planes, 4096x4096 spp 4: 2.2 ms
+    // scheduled (probe and plan for nothing), 1.0 ms in image order.
+    const bool plain_scene = s->dev.has_mesh == 0 && s->dev.has_bezier == 0;  // has_mesh: any tree, a bump floor's included
     const bool reorder = !spill && grid->spp >= 4 && !(grid->flags & CGRT_GRID_NO_REORDER) && n_wt > 1 && n_wt < (1u << 30) &&
-                         (!s->dev.all_spheres || (grid->flags & CGRT_GRID_FORCE_REORDER) || env_force_reorder);
+                         (!plain_scene || (grid->flags & CGRT_GRID_FORCE_REORDER) || env_force_reorder);
     static const long long env_defer_bytes = [] { const char *e = std::getenv("CGRT_DEFER_BYTES"); return e ? std::atoll(e) : 0ll; }();
     static const int env_heavy_div = [] { const char *e = std::getenv("CGRT_HEAVY_DIV"); return e ? std::atoi(e) : 0; }();
     static const int env_units = [] { const char *e = std::getenv("CGRT_UNITS_PER_ITEM"); return e ? std::atoi(e) : 0; }();
