@@ -325,7 +325,13 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                     }
                     my_hits++;
                     if (HPS) {
-                        const unsigned long long k = atomicAdd(hps.count, 1ull);
+                        // one atomic per wave, not per lane (same-address atomics are served one after the other): the lanes
+                        // that are here take consecutive places behind the count their first lane fetched
+                        const unsigned long long here = __ballot(true);
+                        unsigned long long base = 0ull;
+                        if (lane == (int)__ffsll((long long)here) - 1) base = atomicAdd(hps.count, (unsigned long long)__popcll(here));
+                        base = (unsigned long long)__shfl((long long)base, (int)__ffsll((long long)here) - 1);
+                        const unsigned long long k = base + (unsigned long long)__popcll(here & lanes_below);
                         if (k < hps.cap) {
                             double *q = hps.rec + 10 * k;
                             q[0] = hf.x; q[1] = hf.y; q[2] = hf.z;
