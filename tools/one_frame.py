@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development aid: one configuration, a few frames (for rocprofv3 --kernel-trace / --pmc).  python tools/one_frame.py tiny|c4|c3|c5band [spp]"""
+"""Development aid: one configuration, a few frames (for rocprofv3 --kernel-trace / --pmc).  python tools/one_frame.py tiny|c4|c3|c5band|c5floor [spp]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,6 +13,8 @@ elif which == "c4":
     objs, W, H = scenes.scene_dragon(), 4096, 4096
 elif which == "c3":
     objs, W, H = scenes.scene_c3(True), 2048, 2048
+elif which == "c5floor":  # a band of C5 that sees the bump floor and nothing else (light tiles only)
+    objs, W, H, rows, ro = scenes.scene_c5(scenes.stone_texture()), 8192, 8192, 512, 200
 else:
     objs, W, H, rows, ro = scenes.scene_c5(scenes.stone_texture()), 8192, 8192, 256, 3000
 sc = cg.Scene(objs)
