@@ -9,7 +9,7 @@
 using namespace cgrt;
 
 #ifdef CGRT_UTIL
-__device__ unsigned long long g_util[32];
+__device__ unsigned long long g_util[64];
 #define UTILP(k, pred) do { const unsigned long long m_ = __ballot(pred); const unsigned long long a_ = __ballot(true); if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1) { atomicAdd(&g_util[2*(k)], 1ull); atomicAdd(&g_util[2*(k)+1], (unsigned long long)__popcll(m_)); } } while (0)
 #else
 #define UTILP(k, pred) do {} while (0)

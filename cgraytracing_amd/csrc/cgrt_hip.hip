@@ -1294,8 +1294,8 @@ int cgrt_lens_samples(uint64_t seed, const int64_t *pixel, const int32_t *sample
 // development aid (make exp NAME=util DEFS=-DCGRT_UTIL; tools/util_probe.py): lane-utilisation probes, see UTILP in cgrt_device_math.hpp
 extern "C" void cgrt_util_dump(unsigned long long *out) {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_util), sizeof(unsigned long long) * 32);
-    unsigned long long z[32] = {0};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_util), sizeof(unsigned long long) * 64);
+    unsigned long long z[64] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_util), z, sizeof(z));
 }
 #endif

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
         const bool any_pending = __ballot(pending) != 0ull;
         if (notwalking != 0ull && (fresh_left || any_pending) && (__popcll(notwalking) >= g.pw_refill || notwalking == ~0ull)) {
             if (any_pending) {
+                UTILP(19, pending);
                 // the rest of the scene walk (main.cpp:55-63): every object in order, the mesh's hit at the mesh's position
                 double bt = kInf;
                 int bid = -1;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
             const int u = unit_next + (int)__popcll(idle & lanes_below);
             unit_next += (int)__popcll(idle);
             bool fresh = !active && u < unit_end && !queue_empty;
+            UTILP(20, fresh);
             if (fresh) {
                 const int unit_pix = u & 63, unit_smp = u >> 6;
                 const uint32_t wt = load_uniform(g.order + hrank);
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
             const bool inner = active && nxt < 0 && nxt != kWideNone;
             if (__ballot(inner) == 0ull) break;
             if (inner) {
+                UTIL(16);
                 const float4 *q = reinterpret_cast<const float4 *>(wn + (~nxt));
                 const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
                 const int4 ref = reinterpret_cast<const int4 *>(q)[6];
@@ -282,9 +285,11 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
         const bool leaf = active && nxt >= 0;
         if (__ballot(leaf) != 0ull) {
             if (leaf) {
+                UTIL(17);
                 const OTriRec *tp = otris + (nxt >> 4);
                 const int cnt = nxt & 15;
                 for (int k = 0; k < cnt; k++) {
+                    UTIL(18);
                     const V3 pa = ld3(tp[k].t.pa), e1 = ld3(tp[k].t.e1), e2 = ld3(tp[k].t.e2);
                     const int2 rank = *reinterpret_cast<const int2 *>(&tp[k].k);  // k, leaf
                     const V3 s = pa - o;
