@@ -472,13 +472,19 @@ int cgrt_scene_commit(cgrt_scene *s, int device) {
         d.light_ok = (planes_plain && special && !d.all_spheres) ? 1 : 0;
         d.light_trees = plane_trees ? 1 : 0;  // the light variant then needs the tree / height-field code (not Bezier, not glass)
         d.light_hf_only = plane_trees ? 1 : 0;
-        // the LEADING run of >= 3 axis-aligned planes without a bump tree, all in the LDS list
+        // the first run of >= 3 axis-aligned planes without a bump tree, with nothing but other planes in front of it, all in the LDS list
         d.prun_begin = d.prun_end = 0;
         static const bool env_no_plane_run = [] { const char *e = std::getenv("CGRT_NO_PLANE_RUN"); return e && *e && *e != '0'; }();
         if (!env_no_plane_run) {
-            int j = 0;
-            while (j < d.n_lds && H.objs[(size_t)j].kind == KIND_PLANE && H.objs[(size_t)j].axis >= 0 && H.objs[(size_t)j].tree < 0) j++;
-            if (j >= 3) d.prun_end = j;
+            auto eligible = [&](int j) { return H.objs[(size_t)j].kind == KIND_PLANE && H.objs[(size_t)j].axis >= 0 && H.objs[(size_t)j].tree < 0; };
+            int b = 0;  // planes of any sort may stand in front of the run (a bump floor), nothing else
+            while (b < d.n_lds && H.objs[(size_t)b].kind == KIND_PLANE && !eligible(b)) b++;
+            int j = b;
+            while (j < d.n_lds && eligible(j)) j++;
+            if (j - b >= 3) {
+                d.prun_begin = b;
+                d.prun_end = j;
+            }
         }
         for (auto &o : H.objs)
             if (o.kind == KIND_PLANE && o.tree >= 0 && !(o.transp < kEps && trees[(size_t)o.tree].hfield >= 0)) d.light_hf_only = 0;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kThreads, 4) void primary_walk_kernel(DeviceScene s
                 // the leading run of axis-aligned planes as a group, as in intersect_scene (cgrt_scene_walk.hpp plane_run)
                 int i_first = 0, run_end = 0;
                 bool run_unsure = false;
-                if (sc.prun_end > 0 && pw.obj >= sc.prun_end) {
+                if (sc.prun_end > 0 && sc.prun_begin == 0 && pw.obj >= sc.prun_end) {
                     run_end = sc.prun_end;
                     const PlaneRunHit ph = plane_run(lobjs, 0, run_end, o, d);
                     run_unsure = ph.unsure;

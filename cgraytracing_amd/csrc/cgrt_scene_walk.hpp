@@ -287,13 +287,21 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
     // 1/d for the box tests: three fp64 divisions (~100 instructions), paid only by waves that reach a tree
     V3 inv = mk(0, 0, 0);
     bool inv_ready = false;  // wave-uniform
-    // The leading run of axis-aligned planes (plane_run above), before the loop: when every lane of the wave is sure of its
-    // result the loop starts behind the run; otherwise it starts at 0 and the run's planes count for the unsure lanes only.
-    bool run_unsure = false;
-    int run_end = 0, i_first = 0;
-    if (!HFONLY && !SPH && sc.prun_end > 0) {  // (wave-uniform)
+    // The run of axis-aligned planes (plane_run above), before the loop.  When every lane of the wave is sure of its result the
+    // loop passes over the run (and starts behind it if the run leads the list); otherwise the run's planes count for the unsure
+    // lanes only.  Objects in FRONT of the run (planes with a bump tree: C5's floor) are then tested after the run's winner is
+    // known, so a tie goes to them explicitly -- in the list's order they would have been there first (main.cpp:57) -- and
+    // their bump walk starts with the nearest wall as its bound.
+    // A run behind other planes (FRONT) is compiled into the HFONLY and the Bezier variants only -- the two launches of C5, whose
+    // floor carries a bump tree (share at spp 256 219.7 -> 212.0 ms) --: in the other variants its two tests per object cost the
+    // runs that lead the list 2 % (C4 full size 86.7 -> 88.6 ms), so there such a run is left to the loop.
+    constexpr bool FRONT = HFONLY || BEZ;
+    bool run_unsure = false, run_skip = false;
+    int run_begin = 0, run_end = 0, i_first = 0;
+    if (!SPH && sc.prun_end > 0 && (FRONT || sc.prun_begin == 0)) {  // (wave-uniform)
+        run_begin = FRONT ? sc.prun_begin : 0;
         run_end = sc.prun_end;
-        const PlaneRunHit ph = plane_run(objs, 0, run_end, o, d);
+        const PlaneRunHit ph = plane_run(objs, run_begin, run_end, o, d);
         run_unsure = ph.unsure;
         if (!ph.unsure && ph.id >= 0 && ph.len > 0) {  // best.t == kInf here: `len < nearest` is the loop's own test
             if (ph.len < best.t) {
@@ -303,7 +311,8 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                 nsrc = 1;
             }
         }
-        if (__ballot(run_unsure) == 0ull) i_first = run_end;
+        run_skip = __ballot(run_unsure) == 0ull;
+        if (run_skip && run_begin == 0) i_first = run_end;
     }
     for (int i = i_first; i < (SPILL ? n_objs : n_lds); i++) {
         const ObjRec *obp = objs + i;
@@ -318,8 +327,9 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
             obp = aux.spill;
         }
         const ObjRec &ob = *obp;
+        if (FRONT && run_skip && i >= run_begin && i < run_end) continue;  // (uniform; only met when the run does not lead the list)
         // inside the plane run (some lane was unsure): only the unsure lanes take a plane's result from here
-        const bool planes_one_by_one = !(i < run_end) || run_unsure;
+        const bool planes_one_by_one = !((!FRONT || i >= run_begin) && i < run_end) || run_unsure;
         const int kind = __builtin_amdgcn_readfirstlane(ob.kind);
         if (kind == KIND_SPHERE) {
             const double len = sphere_len(ob, o, d);
@@ -353,7 +363,8 @@ __device__ __forceinline__ SceneHit intersect_scene(const ObjRec *__restrict__ o
                     }
                 }
             }
-            if (planes_one_by_one && ph && len < best.t) {
+            // (a plane in front of the run meets the run's winner, not the other way round: it keeps a tie)
+            if (planes_one_by_one && ph && (len < best.t || (FRONT && i < run_begin && len == best.t && best.id >= run_begin))) {
                 best.t = len;
                 best.id = i;
                 best.n = nrm;
