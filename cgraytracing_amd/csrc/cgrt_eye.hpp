@@ -50,6 +50,32 @@ struct HitpointSink {
     unsigned long long cap;
 };
 
+// Whether this wave of a tile workgroup has a wave tile to render in this launch -- the decisions trace_grid_body makes below,
+// ahead of everything else: a workgroup none of whose waves has one (tiles of the other launch of a light / full pair, heavy
+// tiles, tiles outside the image: three quarters of a probe launch's workgroups on C3) leaves before it stages the object list
+// and the node cache in LDS.
+template <int NT>
+__device__ __forceinline__ bool wave_has_tile(const GridParams &g, int tile_block, int tile_grid) {
+    using TG = TileGeom<NT>;
+    const int wave = threadIdx.x >> 6;
+    const int wtiles_x = (g.W + kWaveTileW - 1) / kWaveTileW, wtiles_y = (g.rows + kWaveTileH - 1) / kWaveTileH;
+    int tile_x, tile_y;
+    if (tile_grid < 0) {
+        const int tiles_x = (g.W + TG::W - 1) / TG::W;
+        tile_x = tile_block % tiles_x;
+        tile_y = tile_block / tiles_x;
+    } else {
+        const int tile_blocks = tile_grid / g.chunks;
+        if (!tile_of_block(g, tile_block % tile_blocks, tile_x, tile_y, TG::W, TG::H)) return false;
+    }
+    const int wx = tile_x * (TG::W / kWaveTileW) + (NT == 256 ? (wave & 1) : 0);
+    const int wy = tile_y * (TG::H / kWaveTileH) + (NT == 256 ? (wave >> 1) : 0);
+    if (!(wx < wtiles_x && wy < wtiles_y)) return false;
+    if (g.hidx && g.hidx[wy * wtiles_x + wx] >= 0) return false;
+    if (g.light && (g.light[wy * wtiles_x + wx] != 0) != (g.light_mode != 0)) return false;
+    return true;
+}
+
 // The body of the eye pass for one workgroup.  HEAVY selects how the waves get their work (see GridParams): false -- each
 // wave owns one wave tile (16x4 pixels, one per lane) and every lane runs its pixel's samples; true -- the waves serve the
 // queue of heavy-tile items, lanes drawing (pixel, sample) units.  tile_block / tile_grid: this workgroup's index among the
@@ -60,6 +86,9 @@ __device__ __forceinline__ void trace_grid_body(const DeviceScene &sc, const Gri
                                                 const HitpointSink &hps, int tile_block, int tile_grid) {
     using TG = TileGeom<NT>;
     const long long tl_t0 = g.timeline ? wall_clock64() : 0;
+    if (!HEAVY && !g.timeline) {  // (the timeline, a development aid, wants a record from every workgroup)
+        if (!__syncthreads_or((int)wave_has_tile<NT>(g, tile_block, tile_grid))) return;
+    }
     // LDS carve-up: [ pending-ray levels (GLASS) | objs | Bezier scratch | node cache ]
     extern __shared__ __align__(16) unsigned char lds_raw[];
     ObjRec *lobjs = reinterpret_cast<ObjRec *>(lds_raw + (GLASS ? TG::stack_bytes : 0));  // n_objs records
