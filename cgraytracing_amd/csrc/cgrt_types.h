@@ -195,6 +195,7 @@ struct DeviceScene {
     int32_t prim_finish;    // prim_obj >= 0 and no plane carries a bump tree: primary_walk_kernel may complete units (cgrt_primwalk.hpp)
     int32_t prun_begin, prun_end;  // objects [prun_begin, prun_end): >= 3 axis-aligned planes without a bump tree, tested as a group
                                    // (cgrt_scene_walk.hpp plane_run), only planes in front of them; prun_end == 0: none
+    int32_t single_ray;     // every plane and sphere is diffuse and there is no mesh and no Bezier object: every ray tree is one ray
     int32_t light_hf_only;  // light_trees and every plane's tree is an opaque bump floor with a grid (hfield): the light variant needs the
                             // height-field walk and nothing else of the tree code (HFONLY)
 };
