@@ -562,6 +562,25 @@ def test_random_scenes_match_oracle_exactly(gpu_ready, orc, seed):
     assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
 
 
+@pytest.mark.parametrize("bump", [False, True])
+def test_single_ray_scenes_match_oracle_exactly(gpu_ready, orc, bump):
+    """Diffuse planes (the floor bump-mapped or plainly textured) and diffuse spheres: every ray tree is one ray, the launch stays
+    in image order at any sample count (DeviceScene::single_ray) and the walls behind a bump floor form the plane group's run.
+    Accumulator, hit counts and ray count equal the oracle's."""
+    import cgraytracing_amd as cg
+    objs = scenes.planes(scenes.chessboard_texture(bump)) + [scenes.Sphere((4.0, -14.0, 28.0), 5.0, (0.8, 0.6, 0.4), 0.0, 0.0),
+                                                             scenes.Sphere((-9.0, -16.0, 33.0), 3.0, (0.3, 0.7, 0.9), 0.0, 0.0)]
+    W, H, spp = 96, 64, 6
+    for cam in (scenes.cam_pinhole(), scenes.cam_dof()):
+        want = BackendScene(orc, objs).trace_grid(cam, W, H, spp, 5, seed=99)
+        with cg.Scene(objs) as sc:
+            assert "sched" not in sc.kernel_variant(W, H, spp, cam)
+            got = sc.trace_grid_host(W, H, spp, cam, 5, 99)
+        assert got["nrays"] == want["nrays"] == W * H * spp
+        assert np.array_equal(got["nhit"], want["nhit"])
+        assert np.array_equal(got["rgb"], to_acc32(want["acc_sum"], spp))
+
+
 @pytest.mark.parametrize("variant", ["edges", "origin_in_a_plane", "thin_lens"])
 def test_plane_group_test_edges_corners_and_degenerate_rays(gpu_ready, orc, variant):
     """The leading run of axis-aligned planes is tested as a group (cgrt_scene_walk.hpp plane_run): approximate distances pick
